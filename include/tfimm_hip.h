@@ -1,0 +1,225 @@
+/*
+ * tfimm_hip.h -- C ABI of libtfimm_hip.so, the MI355X (gfx950) forward-path kernels that
+ * stand in for the TensorFlow ops tfimm's model code calls.
+ *
+ * The reference (martinsbruveris/tensorflow-image-models) has no native layer: every
+ * arithmetic op is a tf.* / tf.keras.layers.* call inside Python model code. Each entry
+ * point below therefore replaces a *TF op call site* (cited per function, paths relative
+ * to the reference checkout) rather than an existing FFI symbol.  INTEGRATION.md shows the
+ * ctypes stub a tfimm maintainer would add.
+ *
+ * Conventions
+ *   - plain C: pointers + ints, no C++/torch types.  All pointers are DEVICE pointers
+ *     unless a name ends in _host.  The caller owns every buffer.
+ *   - activations: bf16 (uint16 storage), NHWC / (rows, channels) row-major.
+ *   - weights are pre-packed by the host side (see tfimm/engine/pack.py):
+ *       GEMM/conv weights  Wt[N][ldw]  bf16, K contiguous ("B transposed"),
+ *       bias / norm params  fp32.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *     null stream).  Return value: 0 on success, otherwise a negative TFIMM_E* code or a
+ *     positive hipError_t; tfimm_hip_last_error() returns a static message for the last
+ *     failure on the calling thread.  Nothing throws or aborts across the boundary.
+ */
+#ifndef TFIMM_HIP_H
+#define TFIMM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFIMM_HIP_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define TFIMM_API __attribute__((visibility("default")))
+#else
+#define TFIMM_API
+#endif
+
+#define TFIMM_EINVAL (-1)   /* bad descriptor (shape/alignment/flag)            */
+#define TFIMM_EUNSUP (-2)   /* valid request this build has no kernel for       */
+
+/* activation codes (reference tfimm/layers/factory.py:6-13 act_layer_factory) */
+enum {
+  TFIMM_ACT_NONE = 0,     /* "linear"                                   */
+  TFIMM_ACT_RELU = 1,
+  TFIMM_ACT_GELU = 2,     /* exact erf GELU (keras gelu approximate=False) */
+  TFIMM_ACT_SWISH = 3,    /* x * sigmoid(x)                             */
+  TFIMM_ACT_SIGMOID = 4,
+  TFIMM_ACT_RELU6 = 5,
+  TFIMM_ACT_TANH = 6
+};
+
+/* A-operand addressing modes of tfimm_hip_gemm */
+enum {
+  TFIMM_A_DENSE = 0,      /* A[m][k] = a[m*lda + k]                                   */
+  TFIMM_A_CONV = 1,       /* implicit-GEMM gather from NHWC, Cin % 8 == 0             */
+  TFIMM_A_CONV_C4 = 2     /* implicit-GEMM gather from NHWC with Cin == 4 (padded RGB) */
+};
+
+TFIMM_API int tfimm_hip_abi_version(void);
+TFIMM_API const char* tfimm_hip_last_error(void);
+/* Fills name[len] with e.g. "gfx950:sramecc+:xnack-"; returns CU count or <0. */
+TFIMM_API int tfimm_hip_device_info(int device, char* name, int len);
+
+/* ---------------------------------------------------------------------------------------
+ * tfimm_hip_gemm: out[M][N] = epilogue( A[M][K] . Wt[N][K]^T )            (MFMA, bf16->fp32)
+ *
+ *   epilogue(v)[m][n] = v + bias[n]                      (bias may be NULL)
+ *                       -> act(.)  unless act_after_res
+ *                       -> + residual[rm][n]             (residual may be NULL;
+ *                                                         rm = res_mod ? m % res_mod : m)
+ *                       -> act(.)  if act_after_res
+ *   stored to out[om][n], om = remap_in ? (m / remap_in) * remap_out + m % remap_in + remap_off : m,
+ *   as bf16 (out_f32 == 0) or fp32.
+ *
+ * Replaces, in the reference:
+ *   tf.keras.layers.Dense                  vit.py:155,169  swin.py:167,197  transformers.py:209-212
+ *   Conv2D 1x1 / kxk (+ZeroPadding2D) + BatchNormalization(inference, folded) + Activation
+ *                                          resnet.py:220-258,315-330,505-512  efficientnet_blocks.py:18-63
+ *   PatchEmbeddings conv                   layers/transformers.py:164-165
+ *   residual adds                          vit.py:228,234  resnet.py:289  efficientnet_blocks.py:451
+ *
+ * mode TFIMM_A_CONV:  m = (b*OH + oy)*OW + ox,  k = (ky*KW + kx)*Cin + ci,
+ *     A[m][k] = x[b][oy*stride - pad_t + ky][ox*stride - pad_l + kx][ci]  (0 outside the image)
+ * mode TFIMM_A_CONV_C4: Cin == 4, k = (ky*KWp + kx)*4 + ci with KWp = KW rounded up to even
+ *     (the packed weight has zero columns for kx >= KW).
+ * a_scale (dense mode only, optional): A[m][k] is multiplied by a_scale[(m / rows_per_image)*K + k]
+ *     before the product -- the SqueezeExcite gate  x * sigmoid(...)  of
+ *     efficientnet_blocks.py:241-248 folded into the projection conv.
+ * ------------------------------------------------------------------------------------- */
+typedef struct tfimm_gemm_desc {
+  const void* a;          /* bf16 */
+  const void* wt;         /* bf16 [N][ldw], zero padded to ldw >= K, ldw % 8 == 0 */
+  const float* bias;      /* [N] or NULL */
+  const void* residual;   /* bf16 [.][ldr] or NULL */
+  void* out;              /* bf16 or fp32 [.][ldc] */
+  const float* a_scale;   /* fp32 [M/rows_per_image][K] or NULL */
+  int32_t M, N, K;
+  int32_t lda, ldw, ldr, ldc;
+  int32_t out_f32;
+  int32_t act, act_after_res;
+  int32_t res_mod;
+  int32_t remap_in, remap_out, remap_off;
+  int32_t mode;
+  int32_t B, H, W, Cin, KH, KW, stride, pad_t, pad_l, OH, OW;
+  int32_t rows_per_image;
+  int32_t tile_hint;      /* 0 = auto; otherwise index into the kernel table (benchmarks) */
+} tfimm_gemm_desc;
+
+TFIMM_API int tfimm_hip_gemm(const tfimm_gemm_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * tfimm_hip_cast_input: float32 / bf16 NHWC image batch -> bf16 NHWC with channels padded
+ * to c_out (zeros).  in_dtype: 0 = fp32, 1 = bf16.  Replaces Keras' implicit input cast
+ * (model(x) accepts float arrays, tests/models/test_factory.py:47-49).
+ * ------------------------------------------------------------------------------------- */
+TFIMM_API int tfimm_hip_cast_input(const void* in, int in_dtype, void* out, int64_t n_pixels,
+                         int c_in, int c_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * tfimm_hip_layernorm: y[r][:] = (x[r][:] - mean) * rsqrt(var + eps) * gamma + beta,
+ * population variance, fp32 statistics.  x row r starts at x + r*x_stride (elements),
+ * y row r at y + r*y_stride.  Replaces tf.keras.layers.LayerNormalization
+ * (layers/factory.py:42-50; call sites vit.py:222,231,452  swin.py:295,322,504).
+ * ------------------------------------------------------------------------------------- */
+TFIMM_API int tfimm_hip_layernorm(const void* x, void* y, const float* gamma, const float* beta,
+                        int64_t rows, int d, int64_t x_stride, int64_t y_stride, float eps,
+                        void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * tfimm_hip_attention: fused softmax(scale * Q K^T [+ bias] [+ mask]) V per (sequence, head),
+ * reading q/k/v straight out of the packed QKV projection  qkv[row][3][heads][hd]  and
+ * writing out[row][heads*hd].  fp32 softmax, bf16 P.
+ *
+ * window == 0: global attention, sequence s = image, token t -> row s*n_tokens + t.
+ *     Replaces vit.py:156-167 (reshape/transpose, scale*matmul, softmax, matmul, merge).
+ * window  > 0: Swin (shifted-)window attention on a res_h x res_w token grid, sequence =
+ *     (image, window); token (ty,tx) of window (wy,wx) is grid position
+ *     ((wy*window+ty+shift) % res_h, (wx*window+tx+shift) % res_w) -- i.e. tf.roll(-shift),
+ *     window_partition, window_reverse and tf.roll(+shift) (swin.py:72-108,295-318) are
+ *     folded into the load/store index map.  rel_bias[heads][n][n] (fp32, n = window^2) is
+ *     the gathered relative_position_bias (swin.py:175-184); when shift > 0 the -100 mask of
+ *     swin.py:249-273 is recomputed from region ids.
+ * ------------------------------------------------------------------------------------- */
+typedef struct tfimm_attn_desc {
+  const void* qkv;        /* bf16 [rows][3*heads*hd] */
+  void* out;              /* bf16 [rows][heads*hd]   */
+  const float* rel_bias;  /* fp32 [heads][n][n] or NULL */
+  int32_t batch;          /* images */
+  int32_t n_tokens;       /* tokens per image (global) / res_h*res_w (window) */
+  int32_t heads, hd;
+  float scale;
+  int32_t window, shift, res_h, res_w;
+} tfimm_attn_desc;
+
+TFIMM_API int tfimm_hip_attention(const tfimm_attn_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * tfimm_hip_maxpool: k x k / stride max pool with symmetric zero padding `pad`, NHWC bf16.
+ * Padding contributes ZEROS (the reference pads with ZeroPadding2D and pools VALID,
+ * resnet.py:538-540), not -inf.
+ * ------------------------------------------------------------------------------------- */
+TFIMM_API int tfimm_hip_maxpool(const void* x, void* y, int B, int H, int W, int C, int k, int stride,
+                      int pad, int OH, int OW, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * tfimm_hip_mean_rows: y[b][c] = mean_r x[b][r][c], r < R.  out_f32: 0 bf16, 1 fp32.
+ * GlobalAveragePooling2D / 1D (layers/classifier.py:35, swin.py:506) and the SE squeeze
+ * (efficientnet_blocks.py:242).
+ * ------------------------------------------------------------------------------------- */
+TFIMM_API int tfimm_hip_mean_rows(const void* x, void* y, int B, int R, int C, int out_f32, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * tfimm_hip_bcast_rows: dst[(b*dst_rows_per_image + t)][:] = src[t][:], t < n_rows, b < B.
+ * Writes the (cls [, dist]) token rows, already summed with their pos_embed rows on the
+ * host (vit.py:427-434 tf.repeat / tf.concat / + pos_embed).
+ * ------------------------------------------------------------------------------------- */
+TFIMM_API int tfimm_hip_bcast_rows(const void* src, void* dst, int B, int n_rows, int d,
+                         int dst_rows_per_image, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * tfimm_hip_dwconv: depthwise k x k conv, stride s, explicit (pad_t, pad_l) zero padding,
+ * NHWC bf16, folded-BN scale already in w, + bias, + activation.  w: fp32 [k*k][C].
+ * Optionally accumulates per-(image, channel) sums of the OUTPUT into sum_out (fp32 [B][C],
+ * must be zeroed by the caller) -- the SE squeeze fused into the producer.
+ * Replaces DepthwiseConv2D + BatchNormalization + Activation
+ * (efficientnet_blocks.py:350-352,443-445; convnext.py:191-197 with act none).
+ * ------------------------------------------------------------------------------------- */
+TFIMM_API int tfimm_hip_dwconv(const void* x, const float* w, const float* bias, void* y, float* sum_out,
+                     int B, int H, int W, int C, int k, int stride, int pad_t, int pad_l,
+                     int OH, int OW, int act, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * tfimm_hip_se_gate: gate[b][c] = gate_act( W2 . act( W1 . mean[b] + b1 ) + b2 )[c]
+ * with mean[b][c] = sums[b][c] * inv_count.  w1: fp32 [rd][C], w2: fp32 [C][rd].
+ * SqueezeExcite.call (efficientnet_blocks.py:241-248) / SEModule.call (layers/attention.py:66-74)
+ * minus the final multiply, which is fused into the consumer (a_scale of tfimm_hip_gemm)
+ * or done by tfimm_hip_scale_channels.
+ * ------------------------------------------------------------------------------------- */
+TFIMM_API int tfimm_hip_se_gate(const float* sums, float inv_count, const float* w1, const float* b1,
+                      const float* w2, const float* b2, float* gate, int B, int C, int rd,
+                      int act, int gate_act, void* stream);
+
+/* y[b][r][c] = x[b][r][c] * gate[b][c] (+ residual, then relu if act_after != 0) */
+TFIMM_API int tfimm_hip_scale_channels(const void* x, const float* gate, const void* residual, void* y,
+                             int B, int R, int C, int act_after, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * tfimm_hip_patch_merge_ln: Swin PatchMerging front half (swin.py:352-359): gather the 2x2
+ * neighbourhood in the order (0,0),(1,0),(0,1),(1,1) -> 4C channels, LayerNorm(4C).
+ * x: bf16 [B][H*W][C]; y: bf16 [B][(H/2)*(W/2)][4C].
+ * ------------------------------------------------------------------------------------- */
+TFIMM_API int tfimm_hip_patch_merge_ln(const void* x, void* y, const float* gamma, const float* beta,
+                             int B, int H, int W, int C, float eps, void* stream);
+
+/* Elementwise y = act(x + bias?)  -- used by paths with no producer to fuse into. */
+TFIMM_API int tfimm_hip_bias_act(const void* x, const float* bias, void* y, int64_t rows, int C, int act,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFIMM_HIP_H */

@@ -1,0 +1,82 @@
+// Shared device helpers for the tfimm_hip kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/tfimm_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef uint16_t bf16_t;
+
+// ---- error plumbing (host) ---------------------------------------------------------
+void tfimm_set_error(const char* fmt, ...);
+#define TFIMM_FAIL(code, ...)        \
+  do {                               \
+    tfimm_set_error(__VA_ARGS__);    \
+    return (code);                   \
+  } while (0)
+#define TFIMM_HIP_CHECK(expr)                                                      \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess) {                                                        \
+      tfimm_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),       \
+                      __FILE__, __LINE__);                                         \
+      return (int)_e;                                                              \
+    }                                                                              \
+  } while (0)
+#define TFIMM_LAUNCH_CHECK() TFIMM_HIP_CHECK(hipGetLastError())
+
+// ---- bf16 <-> fp32 -----------------------------------------------------------------
+__device__ __forceinline__ float bf2f(uint32_t h) { return __uint_as_float(h << 16); }
+// round-to-nearest-even, NaN kept quiet
+__device__ __forceinline__ uint32_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return f2bf(lo) | (f2bf(hi) << 16);
+}
+__device__ __forceinline__ void unpack8(const uint4& u, float* f) {
+  f[0] = bf2f(u.x & 0xffffu); f[1] = bf2f(u.x >> 16);
+  f[2] = bf2f(u.y & 0xffffu); f[3] = bf2f(u.y >> 16);
+  f[4] = bf2f(u.z & 0xffffu); f[5] = bf2f(u.z >> 16);
+  f[6] = bf2f(u.w & 0xffffu); f[7] = bf2f(u.w >> 16);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 u;
+  u.x = pack_bf2(f[0], f[1]); u.y = pack_bf2(f[2], f[3]);
+  u.z = pack_bf2(f[4], f[5]); u.w = pack_bf2(f[6], f[7]);
+  return u;
+}
+
+// ---- activations (reference tfimm/layers/factory.py:6-13) -----------------------------
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case TFIMM_ACT_RELU: return fmaxf(v, 0.f);
+    case TFIMM_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    case TFIMM_ACT_SWISH: return v / (1.f + __expf(-v));
+    case TFIMM_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+    case TFIMM_ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);
+    case TFIMM_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+// ---- wave64 reductions ---------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

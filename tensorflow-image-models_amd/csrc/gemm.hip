@@ -1,0 +1,132 @@
+// tfimm_hip_gemm host side: descriptor validation, tile selection, launch.
+// Kernel: gemm_kernel.h; per-tile instantiations: gemm_inst.hip.
+#include "gemm_kernel.h"
+
+using namespace tfimm_gemm;
+
+#define TFIMM_DECL(ID, BM_, BN_, WM_, WN_) extern "C" const TileCfg tfimm_gemm_tile_##ID;
+TFIMM_GEMM_TILES(TFIMM_DECL)
+#undef TFIMM_DECL
+
+namespace {
+
+const TileCfg* tile_table(int i) {
+#define TFIMM_CASE(ID, BM_, BN_, WM_, WN_) \
+  case ID: return &tfimm_gemm_tile_##ID;
+  switch (i) {
+    TFIMM_GEMM_TILES(TFIMM_CASE)
+    default: return nullptr;
+  }
+#undef TFIMM_CASE
+}
+
+int g_num_cu = 0;
+
+int num_cu() {
+  if (g_num_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      g_num_cu = prop.multiProcessorCount;
+    if (g_num_cu <= 0) g_num_cu = 256;
+  }
+  return g_num_cu;
+}
+
+// tile ids: 0 128x128, 1 128x64, 2 64x64, 3 256x128, 4 128x256, 5 64x128
+int pick_tile(const tfimm_gemm_desc& d, int kmode) {
+  if (kmode == K_DENSE_SCALAR) return 2;
+  if (d.tile_hint > 0 && d.tile_hint <= TFIMM_GEMM_NUM_TILES && tile_table(d.tile_hint - 1)->fn[kmode])
+    return d.tile_hint - 1;
+  const int cus = num_cu();
+  const int64_t M = d.M, N = d.N;
+  auto blocks = [&](int bm, int bn) { return cdiv64(M, bm) * cdiv64(N, bn); };
+  // prefer the biggest tile that still gives every CU >= 2 blocks
+  if (N > 64 && blocks(128, 128) >= 2 * cus) return 0;
+  if (N <= 64 && blocks(128, 64) >= 2 * cus) return 1;
+  if (N > 64 && blocks(64, 128) >= cus) return 5;
+  if (blocks(128, 64) >= 2 * cus) return 1;
+  return 2;
+}
+
+}  // namespace
+
+extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
+  if (!dp) TFIMM_FAIL(TFIMM_EINVAL, "gemm: null descriptor");
+  const tfimm_gemm_desc& d = *dp;
+  if (!d.a || !d.wt || !d.out) TFIMM_FAIL(TFIMM_EINVAL, "gemm: null a/wt/out pointer");
+  if (d.M <= 0 || d.N <= 0 || d.K <= 0) TFIMM_FAIL(TFIMM_EINVAL, "gemm: M=%d N=%d K=%d", d.M, d.N, d.K);
+  if (d.ldw < d.K || (d.ldw & 7)) TFIMM_FAIL(TFIMM_EINVAL, "gemm: ldw=%d must be >= K=%d and a multiple of 8", d.ldw, d.K);
+  if (((uintptr_t)d.wt & 15)) TFIMM_FAIL(TFIMM_EINVAL, "gemm: wt must be 16-byte aligned");
+  if (d.ldc < d.N) TFIMM_FAIL(TFIMM_EINVAL, "gemm: ldc=%d < N=%d", d.ldc, d.N);
+  if (d.mode < 0 || d.mode > 2) TFIMM_FAIL(TFIMM_EINVAL, "gemm: mode=%d", d.mode);
+  if (d.remap_in < 0 || d.res_mod < 0) TFIMM_FAIL(TFIMM_EINVAL, "gemm: negative remap/res_mod");
+  if (d.bias && ((uintptr_t)d.bias & 15)) TFIMM_FAIL(TFIMM_EINVAL, "gemm: bias must be 16-byte aligned");
+
+  GemmArgs g;
+  g.a = (const bf16_t*)d.a; g.wt = (const bf16_t*)d.wt; g.bias = d.bias;
+  g.residual = (const bf16_t*)d.residual; g.out = d.out; g.a_scale = d.a_scale;
+  g.M = d.M; g.N = d.N; g.K = d.K;
+  g.lda = d.lda; g.ldw = d.ldw; g.ldr = d.ldr; g.ldc = d.ldc;
+  g.out_f32 = d.out_f32; g.act = d.act; g.act_after_res = d.act_after_res; g.res_mod = d.res_mod;
+  g.remap_in = d.remap_in; g.remap_out = d.remap_out; g.remap_off = d.remap_off;
+  g.B = d.B; g.H = d.H; g.W = d.W; g.Cin = d.Cin; g.KH = d.KH; g.KW = d.KW;
+  g.KWp = (d.KW + 1) & ~1;
+  g.stride = d.stride; g.pad_t = d.pad_t; g.pad_l = d.pad_l; g.OH = d.OH; g.OW = d.OW;
+  g.rows_per_image = d.rows_per_image;
+
+  int kmode;
+  if (d.mode == TFIMM_A_DENSE) {
+    if (d.lda < d.K) TFIMM_FAIL(TFIMM_EINVAL, "gemm: lda=%d < K=%d", d.lda, d.K);
+    const bool vec = ((d.lda & 7) == 0) && ((d.K & 7) == 0) && (((uintptr_t)d.a & 15) == 0);
+    if (d.a_scale) {
+      if (!vec || d.rows_per_image <= 0 || ((uintptr_t)d.a_scale & 15))
+        TFIMM_FAIL(TFIMM_EINVAL, "gemm: a_scale needs aligned K %% 8 == 0 rows and rows_per_image > 0");
+      kmode = K_DENSE_SCALE;
+    } else {
+      kmode = vec ? K_DENSE : K_DENSE_SCALAR;
+    }
+  } else {
+    if (d.a_scale) TFIMM_FAIL(TFIMM_EINVAL, "gemm: a_scale only in dense mode");
+    if (d.B <= 0 || d.H <= 0 || d.W <= 0 || d.KH <= 0 || d.KW <= 0 || d.stride <= 0 || d.OH <= 0 || d.OW <= 0)
+      TFIMM_FAIL(TFIMM_EINVAL, "gemm: bad conv geometry");
+    if ((int64_t)d.B * d.OH * d.OW != d.M) TFIMM_FAIL(TFIMM_EINVAL, "gemm: M != B*OH*OW");
+    if (((uintptr_t)d.a & 15)) TFIMM_FAIL(TFIMM_EINVAL, "gemm: conv input must be 16-byte aligned");
+    if (d.mode == TFIMM_A_CONV) {
+      if (d.Cin & 7) TFIMM_FAIL(TFIMM_EINVAL, "gemm: conv mode needs Cin %% 8 == 0 (Cin=%d)", d.Cin);
+      if (d.K != d.KH * d.KW * d.Cin) TFIMM_FAIL(TFIMM_EINVAL, "gemm: K != KH*KW*Cin");
+      kmode = K_CONV;
+    } else {
+      if (d.Cin != 4) TFIMM_FAIL(TFIMM_EINVAL, "gemm: C4 mode needs Cin == 4");
+      if (d.K != d.KH * g.KWp * 4) TFIMM_FAIL(TFIMM_EINVAL, "gemm: K != KH*KWp*4 (K=%d)", d.K);
+      kmode = K_CONV_C4;
+    }
+  }
+  g.res_vec = d.residual ? (((d.ldr & 3) == 0) && (((uintptr_t)d.residual & 7) == 0)) : 0;
+  if (d.out_f32)
+    g.out_vec = ((d.ldc & 3) == 0) && (((uintptr_t)d.out & 15) == 0);
+  else
+    g.out_vec = ((d.ldc & 3) == 0) && (((uintptr_t)d.out & 7) == 0);
+
+  int ti = pick_tile(d, kmode);
+  const TileCfg* t = tile_table(ti);
+  if (!t->fn[kmode]) {  // flavour not built for the picked tile: fall back to 64x64 / 128x64
+    ti = (kmode == K_DENSE_SCALE) ? 1 : 2;
+    t = tile_table(ti);
+    if (!t->fn[kmode]) TFIMM_FAIL(TFIMM_EUNSUP, "gemm: no kernel for flavour %d", kmode);
+  }
+  g.tiles_m = (int)cdiv64(d.M, t->bm);
+  g.tiles_n = (int)cdiv64(d.N, t->bn);
+  const int64_t nblocks = (int64_t)g.tiles_m * g.tiles_n;
+  if (nblocks > 0x7fffffffLL) TFIMM_FAIL(TFIMM_EINVAL, "gemm: grid too large");
+  const size_t lds_bytes = (size_t)(t->bm + t->bn) * BK * 2 * 2;
+  gemm_fn fn = t->fn[kmode];
+  static bool attr_done[TFIMM_GEMM_NUM_TILES][K_NUM] = {};
+  if (!attr_done[ti][kmode]) {
+    TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    attr_done[ti][kmode] = true;
+  }
+  hipLaunchKernelGGL(fn, dim3((unsigned)nblocks), dim3(t->threads), lds_bytes, (hipStream_t)stream, g);
+  TFIMM_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,548 @@
+// Bandwidth-bound row/pixel kernels of the tfimm forward path: input cast, LayerNorm,
+// pooling, token-row broadcast, depthwise conv (+SE squeeze), SE gate, channel scaling,
+// Swin patch-merge + LN.  All NHWC / (rows, channels) bf16 with 16-byte vector access
+// whenever the channel count allows it.  Reference call sites: include/tfimm_hip.h.
+#include "common.h"
+
+#include <cstdarg>
+#include <cstdio>
+
+// ---------------------------------------------------------------------------------------
+// error string + misc C ABI
+// ---------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "ok";
+void tfimm_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* tfimm_hip_last_error(void) { return g_err; }
+extern "C" int tfimm_hip_abi_version(void) { return TFIMM_HIP_ABI_VERSION; }
+extern "C" int tfimm_hip_device_info(int device, char* name, int len) {
+  hipDeviceProp_t prop;
+  TFIMM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  if (name && len > 0) snprintf(name, (size_t)len, "%s", prop.gcnArchName);
+  return prop.multiProcessorCount;
+}
+
+namespace {
+
+constexpr int kMaxBlocks = 256 * 16;  // grid-stride cap: 16 blocks per CU
+
+inline unsigned grid_for(int64_t work_items, int per_block) {
+  int64_t b = cdiv64(work_items, per_block);
+  if (b < 1) b = 1;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  return (unsigned)b;
+}
+
+// ---------------------------------------------------------------------------------------
+// cast_input
+// ---------------------------------------------------------------------------------------
+template <bool IN_BF16>
+__global__ void cast_input_kernel(const void* in, bf16_t* out, int64_t n_pixels, int c_in, int c_out) {
+  for (int64_t px = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; px < n_pixels;
+       px += (int64_t)gridDim.x * blockDim.x) {
+    bf16_t* o = out + px * c_out;
+    for (int c = 0; c < c_out; ++c) {
+      uint32_t v = 0u;
+      if (c < c_in) {
+        if (IN_BF16) v = reinterpret_cast<const bf16_t*>(in)[px * c_in + c];
+        else v = f2bf(reinterpret_cast<const float*>(in)[px * c_in + c]);
+      }
+      o[c] = (bf16_t)v;
+    }
+  }
+}
+
+// RGB fast path: 3 -> 4 channels, one 8-byte store per pixel
+template <bool IN_BF16>
+__global__ void cast_rgb4_kernel(const void* in, uint2* out, int64_t n_pixels) {
+  for (int64_t px = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; px < n_pixels;
+       px += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t r, g, b;
+    if (IN_BF16) {
+      const bf16_t* p = reinterpret_cast<const bf16_t*>(in) + px * 3;
+      r = p[0]; g = p[1]; b = p[2];
+    } else {
+      const float* p = reinterpret_cast<const float*>(in) + px * 3;
+      r = f2bf(p[0]); g = f2bf(p[1]); b = f2bf(p[2]);
+    }
+    out[px] = make_uint2(r | (g << 16), b);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// layernorm: one wave per row, row cached in registers (vector path) or re-read (generic)
+// ---------------------------------------------------------------------------------------
+template <int NCH>  // 16-byte chunks per lane: supports d <= NCH * 512
+__global__ void __launch_bounds__(256) layernorm_vec_kernel(const bf16_t* x, bf16_t* y, const float* gamma,
+                                                            const float* beta, int64_t rows, int d,
+                                                            int64_t xs, int64_t ys, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int nchunks = d >> 3;
+  const float inv_d = 1.f / (float)d;
+  for (int64_t r = wave0; r < rows; r += nwaves) {
+    const uint4* xr = reinterpret_cast<const uint4*>(x + r * xs);
+    float v[NCH][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunks) {
+        const uint4 u = xr[c];
+        unpack8(u, v[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += v[i][e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+      }
+    }
+    const float mean = wave_sum(sum) * inv_d;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunks) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float t = v[i][e] - mean;
+          sq += t * t;
+        }
+      }
+    }
+    const float var = wave_sum(sq) * inv_d;
+    const float rstd = rsqrtf(var + eps);
+    uint4* yr = reinterpret_cast<uint4*>(y + r * ys);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunks) {
+        const float4 g0 = reinterpret_cast<const float4*>(gamma)[2 * c];
+        const float4 g1 = reinterpret_cast<const float4*>(gamma)[2 * c + 1];
+        const float4 b0 = reinterpret_cast<const float4*>(beta)[2 * c];
+        const float4 b1 = reinterpret_cast<const float4*>(beta)[2 * c + 1];
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+        yr[c] = pack8(o);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) layernorm_generic_kernel(const bf16_t* x, bf16_t* y, const float* gamma,
+                                                                const float* beta, int64_t rows, int d,
+                                                                int64_t xs, int64_t ys, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const float inv_d = 1.f / (float)d;
+  for (int64_t r = wave0; r < rows; r += nwaves) {
+    const bf16_t* xr = x + r * xs;
+    float sum = 0.f;
+    for (int c = lane; c < d; c += 64) sum += bf2f(xr[c]);
+    const float mean = wave_sum(sum) * inv_d;
+    float sq = 0.f;
+    for (int c = lane; c < d; c += 64) {
+      const float t = bf2f(xr[c]) - mean;
+      sq += t * t;
+    }
+    const float rstd = rsqrtf(wave_sum(sq) * inv_d + eps);
+    bf16_t* yr = y + r * ys;
+    for (int c = lane; c < d; c += 64)
+      yr[c] = (bf16_t)f2bf((bf2f(xr[c]) - mean) * rstd * gamma[c] + beta[c]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// maxpool (zero padding participates in the max, see header)
+// ---------------------------------------------------------------------------------------
+__global__ void maxpool_vec_kernel(const bf16_t* x, bf16_t* y, int B, int H, int W, int C, int k, int stride,
+                                   int pad, int OH, int OW) {
+  const int cg = C >> 3;
+  const int64_t total = (int64_t)B * OH * OW * cg;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total;
+       id += (int64_t)gridDim.x * blockDim.x) {
+    const int c8 = (int)(id % cg);
+    int64_t t = id / cg;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH);
+    const int b = (int)(t / OH);
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -3.0e38f;
+    for (int ky = 0; ky < k; ++ky) {
+      const int iy = oy * stride - pad + ky;
+      for (int kx = 0; kx < k; ++kx) {
+        const int ix = ox * stride - pad + kx;
+        float v[8];
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+          const uint4 u = *reinterpret_cast<const uint4*>(x + (((int64_t)b * H + iy) * W + ix) * C + c8 * 8);
+          unpack8(u, v);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+      }
+    }
+    *reinterpret_cast<uint4*>(y + (((int64_t)b * OH + oy) * OW + ox) * C + c8 * 8) = pack8(m);
+  }
+}
+
+__global__ void maxpool_generic_kernel(const bf16_t* x, bf16_t* y, int B, int H, int W, int C, int k, int stride,
+                                       int pad, int OH, int OW) {
+  const int64_t total = (int64_t)B * OH * OW * C;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total;
+       id += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(id % C);
+    int64_t t = id / C;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH);
+    const int b = (int)(t / OH);
+    float m = -3.0e38f;
+    for (int ky = 0; ky < k; ++ky)
+      for (int kx = 0; kx < k; ++kx) {
+        const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+          v = bf2f(x[(((int64_t)b * H + iy) * W + ix) * C + c]);
+        m = fmaxf(m, v);
+      }
+    y[id] = (bf16_t)f2bf(m);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// mean over rows: block = (image, 64-channel group...) -- one thread per channel, coalesced
+// across channels, rows split over blockDim.y then reduced through LDS.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mean_rows_kernel(const bf16_t* x, void* y, int B, int R, int C, int out_f32) {
+  __shared__ float part[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int cgroups = (C + 63) / 64;
+  for (int blk = blockIdx.x; blk < B * cgroups; blk += gridDim.x) {
+    const int b = blk / cgroups, c = (blk - b * cgroups) * 64 + cx;
+    float s = 0.f;
+    if (c < C) {
+      const bf16_t* p = x + (int64_t)b * R * C + c;
+      for (int r = ry; r < R; r += 4) s += bf2f(p[(int64_t)r * C]);
+    }
+    part[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+      const float m = (part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx]) / (float)R;
+      if (out_f32) reinterpret_cast<float*>(y)[(int64_t)b * C + c] = m;
+      else reinterpret_cast<bf16_t*>(y)[(int64_t)b * C + c] = (bf16_t)f2bf(m);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void bcast_rows_kernel(const bf16_t* src, bf16_t* dst, int B, int n_rows, int d, int dst_rpi) {
+  const int64_t total = (int64_t)B * n_rows * d;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total;
+       id += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(id % d);
+    const int64_t t = id / d;
+    const int r = (int)(t % n_rows);
+    const int64_t b = t / n_rows;
+    dst[(b * dst_rpi + r) * d + c] = src[(int64_t)r * d + c];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// depthwise conv: thread = (output pixel, 8-channel group); weights fp32 [k*k][C]
+// ---------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ void __launch_bounds__(256) dwconv_kernel(const bf16_t* x, const float* w, const float* bias, bf16_t* y,
+                                                     float* sum_out, int B, int H, int W, int C, int k, int stride,
+                                                     int pad_t, int pad_l, int OH, int OW, int act) {
+  constexpr int G = VEC ? 8 : 1;
+  const int cg = VEC ? (C >> 3) : C;
+  const int64_t total = (int64_t)B * OH * OW * cg;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total;
+       id += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(id % cg) * G;
+    int64_t t = id / cg;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH);
+    const int b = (int)(t / OH);
+    float acc[G];
+#pragma unroll
+    for (int e = 0; e < G; ++e) acc[e] = bias ? bias[c0 + e] : 0.f;
+    for (int ky = 0; ky < k; ++ky) {
+      const int iy = oy * stride - pad_t + ky;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int kx = 0; kx < k; ++kx) {
+        const int ix = ox * stride - pad_l + kx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const bf16_t* xp = x + (((int64_t)b * H + iy) * W + ix) * C + c0;
+        const float* wp = w + (int64_t)(ky * k + kx) * C + c0;
+        if constexpr (VEC) {
+          float v[8];
+          unpack8(*reinterpret_cast<const uint4*>(xp), v);
+          const float4 w0 = reinterpret_cast<const float4*>(wp)[0];
+          const float4 w1 = reinterpret_cast<const float4*>(wp)[1];
+          const float ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += v[e] * ww[e];
+        } else {
+          acc[0] += bf2f(xp[0]) * wp[0];
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < G; ++e) acc[e] = apply_act(acc[e], act);
+    bf16_t* yp = y + (((int64_t)b * OH + oy) * OW + ox) * C + c0;
+    if constexpr (VEC) {
+      const uint4 u = pack8(acc);
+      *reinterpret_cast<uint4*>(yp) = u;
+      if (sum_out) {
+        float r[8];
+        unpack8(u, r);  // squeeze sees the stored (bf16-rounded) activations
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomicAdd(sum_out + (int64_t)b * C + c0 + e, r[e]);
+      }
+    } else {
+      const uint32_t h = f2bf(acc[0]);
+      yp[0] = (bf16_t)h;
+      if (sum_out) atomicAdd(sum_out + (int64_t)b * C + c0, bf2f(h));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// SE gate: one block per image
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) se_gate_kernel(const float* sums, float inv_count, const float* w1,
+                                                      const float* b1, const float* w2, const float* b2,
+                                                      float* gate, int C, int rd, int act, int gate_act) {
+  extern __shared__ float sm[];  // [C] means + [rd] hidden
+  float* mean = sm;
+  float* hid = sm + C;
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) mean[c] = sums[(int64_t)b * C + c] * inv_count;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int j = wave; j < rd; j += nw) {
+    float s = 0.f;
+    const float* wr = w1 + (int64_t)j * C;
+    for (int c = lane; c < C; c += 64) s += wr[c] * mean[c];
+    s = wave_sum(s);
+    if (lane == 0) hid[j] = apply_act(s + (b1 ? b1[j] : 0.f), act);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = b2 ? b2[c] : 0.f;
+    const float* wr = w2 + (int64_t)c * rd;
+    for (int j = 0; j < rd; ++j) s += wr[j] * hid[j];
+    gate[(int64_t)b * C + c] = apply_act(s, gate_act);
+  }
+}
+
+__global__ void scale_channels_kernel(const bf16_t* x, const float* gate, const bf16_t* residual, bf16_t* y, int B,
+                                      int R, int C, int act_after) {
+  const int64_t total = (int64_t)B * R * C;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total;
+       id += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(id % C);
+    const int64_t b = id / ((int64_t)R * C);
+    float v = bf2f(x[id]) * gate[b * C + c];
+    if (residual) v += bf2f(residual[id]);
+    if (act_after) v = fmaxf(v, 0.f);
+    y[id] = (bf16_t)f2bf(v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Swin PatchMerging gather + LayerNorm(4C): one wave per output token
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) patch_merge_ln_kernel(const bf16_t* x, bf16_t* y, const float* gamma,
+                                                             const float* beta, int B, int H, int W, int C,
+                                                             float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int H2 = H / 2, W2 = W / 2, D = 4 * C;
+  const int64_t rows = (int64_t)B * H2 * W2;
+  const float inv_d = 1.f / (float)D;
+  for (int64_t r = wave0; r < rows; r += nwaves) {
+    const int x2 = (int)(r % W2);
+    const int y2 = (int)((r / W2) % H2);
+    const int64_t b = r / ((int64_t)W2 * H2);
+    // concat order x0,x1,x2,x3 = (dy,dx) (0,0),(1,0),(0,1),(1,1)   (swin.py:353-357)
+    auto src = [&](int j) -> float {
+      const int part = j / C, c = j - part * C;
+      const int dy = part & 1, dx = part >> 1;
+      return bf2f(x[((b * H + (2 * y2 + dy)) * W + (2 * x2 + dx)) * C + c]);
+    };
+    float sum = 0.f;
+    for (int j = lane; j < D; j += 64) sum += src(j);
+    const float mean = wave_sum(sum) * inv_d;
+    float sq = 0.f;
+    for (int j = lane; j < D; j += 64) {
+      const float t = src(j) - mean;
+      sq += t * t;
+    }
+    const float rstd = rsqrtf(wave_sum(sq) * inv_d + eps);
+    bf16_t* yr = y + r * D;
+    for (int j = lane; j < D; j += 64) yr[j] = (bf16_t)f2bf((src(j) - mean) * rstd * gamma[j] + beta[j]);
+  }
+}
+
+__global__ void bias_act_kernel(const bf16_t* x, const float* bias, bf16_t* y, int64_t rows, int C, int act) {
+  const int64_t total = rows * C;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total;
+       id += (int64_t)gridDim.x * blockDim.x) {
+    float v = bf2f(x[id]);
+    if (bias) v += bias[id % C];
+    y[id] = (bf16_t)f2bf(apply_act(v, act));
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// C ABI wrappers
+// ---------------------------------------------------------------------------------------
+extern "C" int tfimm_hip_cast_input(const void* in, int in_dtype, void* out, int64_t n_pixels, int c_in,
+                                    int c_out, void* stream) {
+  if (!in || !out || n_pixels <= 0 || c_in <= 0 || c_out < c_in || (in_dtype != 0 && in_dtype != 1))
+    TFIMM_FAIL(TFIMM_EINVAL, "cast_input: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = grid_for(n_pixels, 256);
+  if (c_in == 3 && c_out == 4 && (((uintptr_t)out & 7) == 0)) {
+    if (in_dtype) hipLaunchKernelGGL(cast_rgb4_kernel<true>, dim3(grid), dim3(256), 0, st, in, (uint2*)out, n_pixels);
+    else hipLaunchKernelGGL(cast_rgb4_kernel<false>, dim3(grid), dim3(256), 0, st, in, (uint2*)out, n_pixels);
+  } else {
+    if (in_dtype) hipLaunchKernelGGL(cast_input_kernel<true>, dim3(grid), dim3(256), 0, st, in, (bf16_t*)out, n_pixels, c_in, c_out);
+    else hipLaunchKernelGGL(cast_input_kernel<false>, dim3(grid), dim3(256), 0, st, in, (bf16_t*)out, n_pixels, c_in, c_out);
+  }
+  TFIMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tfimm_hip_layernorm(const void* x, void* y, const float* gamma, const float* beta, int64_t rows,
+                                   int d, int64_t x_stride, int64_t y_stride, float eps, void* stream) {
+  if (!x || !y || !gamma || !beta || rows <= 0 || d <= 0) TFIMM_FAIL(TFIMM_EINVAL, "layernorm: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = grid_for(rows, 4);
+  const bool vec = (d % 8 == 0) && (x_stride % 8 == 0) && (y_stride % 8 == 0) && (((uintptr_t)x & 15) == 0) &&
+                   (((uintptr_t)y & 15) == 0) && (((uintptr_t)gamma & 15) == 0) && (((uintptr_t)beta & 15) == 0) &&
+                   d <= 4096;
+  const bf16_t* xb = (const bf16_t*)x;
+  bf16_t* yb = (bf16_t*)y;
+  if (vec) {
+    if (d <= 512) hipLaunchKernelGGL(layernorm_vec_kernel<1>, dim3(grid), dim3(256), 0, st, xb, yb, gamma, beta, rows, d, x_stride, y_stride, eps);
+    else if (d <= 1024) hipLaunchKernelGGL(layernorm_vec_kernel<2>, dim3(grid), dim3(256), 0, st, xb, yb, gamma, beta, rows, d, x_stride, y_stride, eps);
+    else if (d <= 2048) hipLaunchKernelGGL(layernorm_vec_kernel<4>, dim3(grid), dim3(256), 0, st, xb, yb, gamma, beta, rows, d, x_stride, y_stride, eps);
+    else hipLaunchKernelGGL(layernorm_vec_kernel<8>, dim3(grid), dim3(256), 0, st, xb, yb, gamma, beta, rows, d, x_stride, y_stride, eps);
+  } else {
+    hipLaunchKernelGGL(layernorm_generic_kernel, dim3(grid), dim3(256), 0, st, xb, yb, gamma, beta, rows, d, x_stride, y_stride, eps);
+  }
+  TFIMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tfimm_hip_maxpool(const void* x, void* y, int B, int H, int W, int C, int k, int stride, int pad,
+                                 int OH, int OW, void* stream) {
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || stride <= 0 || pad < 0 || OH <= 0 || OW <= 0)
+    TFIMM_FAIL(TFIMM_EINVAL, "maxpool: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (C % 8 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0);
+  if (vec) {
+    const unsigned grid = grid_for((int64_t)B * OH * OW * (C / 8), 256);
+    hipLaunchKernelGGL(maxpool_vec_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, k, stride, pad, OH, OW);
+  } else {
+    const unsigned grid = grid_for((int64_t)B * OH * OW * C, 256);
+    hipLaunchKernelGGL(maxpool_generic_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, k, stride, pad, OH, OW);
+  }
+  TFIMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tfimm_hip_mean_rows(const void* x, void* y, int B, int R, int C, int out_f32, void* stream) {
+  if (!x || !y || B <= 0 || R <= 0 || C <= 0) TFIMM_FAIL(TFIMM_EINVAL, "mean_rows: bad arguments");
+  const int64_t blocks = (int64_t)B * ((C + 63) / 64);
+  const unsigned grid = (unsigned)(blocks > 65535 * 16 ? 65535 * 16 : blocks);
+  hipLaunchKernelGGL(mean_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, B, R, C, out_f32);
+  TFIMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tfimm_hip_bcast_rows(const void* src, void* dst, int B, int n_rows, int d, int dst_rows_per_image,
+                                    void* stream) {
+  if (!src || !dst || B <= 0 || n_rows <= 0 || d <= 0 || dst_rows_per_image < n_rows)
+    TFIMM_FAIL(TFIMM_EINVAL, "bcast_rows: bad arguments");
+  const unsigned grid = grid_for((int64_t)B * n_rows * d, 256);
+  hipLaunchKernelGGL(bcast_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, B, n_rows, d, dst_rows_per_image);
+  TFIMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tfimm_hip_dwconv(const void* x, const float* w, const float* bias, void* y, float* sum_out, int B,
+                                int H, int W, int C, int k, int stride, int pad_t, int pad_l, int OH, int OW,
+                                int act, void* stream) {
+  if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || stride <= 0 || OH <= 0 || OW <= 0)
+    TFIMM_FAIL(TFIMM_EINVAL, "dwconv: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (C % 8 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0) &&
+                   (((uintptr_t)w & 15) == 0);
+  if (vec) {
+    const unsigned grid = grid_for((int64_t)B * OH * OW * (C / 8), 256);
+    hipLaunchKernelGGL(dwconv_kernel<true>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, w, bias, (bf16_t*)y, sum_out, B, H, W, C, k, stride, pad_t, pad_l, OH, OW, act);
+  } else {
+    const unsigned grid = grid_for((int64_t)B * OH * OW * C, 256);
+    hipLaunchKernelGGL(dwconv_kernel<false>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, w, bias, (bf16_t*)y, sum_out, B, H, W, C, k, stride, pad_t, pad_l, OH, OW, act);
+  }
+  TFIMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tfimm_hip_se_gate(const float* sums, float inv_count, const float* w1, const float* b1,
+                                 const float* w2, const float* b2, float* gate, int B, int C, int rd, int act,
+                                 int gate_act, void* stream) {
+  if (!sums || !w1 || !w2 || !gate || B <= 0 || C <= 0 || rd <= 0) TFIMM_FAIL(TFIMM_EINVAL, "se_gate: bad arguments");
+  const size_t lds = (size_t)(C + rd) * sizeof(float);
+  if (lds > 64 * 1024) TFIMM_FAIL(TFIMM_EUNSUP, "se_gate: C + rd = %d too large", C + rd);
+  hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, sums, inv_count, w1, b1, w2, b2, gate, C, rd, act, gate_act);
+  TFIMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tfimm_hip_scale_channels(const void* x, const float* gate, const void* residual, void* y, int B,
+                                        int R, int C, int act_after, void* stream) {
+  if (!x || !gate || !y || B <= 0 || R <= 0 || C <= 0) TFIMM_FAIL(TFIMM_EINVAL, "scale_channels: bad arguments");
+  const unsigned grid = grid_for((int64_t)B * R * C, 256);
+  hipLaunchKernelGGL(scale_channels_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gate, (const bf16_t*)residual, (bf16_t*)y, B, R, C, act_after);
+  TFIMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tfimm_hip_patch_merge_ln(const void* x, void* y, const float* gamma, const float* beta, int B,
+                                        int H, int W, int C, float eps, void* stream) {
+  if (!x || !y || !gamma || !beta || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0)
+    TFIMM_FAIL(TFIMM_EINVAL, "patch_merge_ln: bad arguments");
+  const unsigned grid = grid_for((int64_t)B * (H / 2) * (W / 2), 4);
+  hipLaunchKernelGGL(patch_merge_ln_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, gamma, beta, B, H, W, C, eps);
+  TFIMM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tfimm_hip_bias_act(const void* x, const float* bias, void* y, int64_t rows, int C, int act,
+                                  void* stream) {
+  if (!x || !y || rows <= 0 || C <= 0) TFIMM_FAIL(TFIMM_EINVAL, "bias_act: bad arguments");
+  const unsigned grid = grid_for(rows * C, 256);
+  hipLaunchKernelGGL(bias_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, bias, (bf16_t*)y, rows, C, act);
+  TFIMM_LAUNCH_CHECK();
+  return 0;
+}

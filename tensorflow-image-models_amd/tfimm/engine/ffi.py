@@ -1,0 +1,92 @@
+"""ctypes binding of libtfimm_hip.so (C ABI: include/tfimm_hip.h).
+
+The library is the ONLY compute path of this package: if it cannot be loaded the import of
+this module raises -- there is deliberately no CPU or PyTorch fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtfimm_hip.so")
+
+ACT = {
+    "": 0, "linear": 0, "none": 0, None: 0,
+    "relu": 1, "gelu": 2, "swish": 3, "sigmoid": 4, "relu6": 5, "tanh": 6,
+}
+A_DENSE, A_CONV, A_CONV_C4 = 0, 1, 2
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("a", C.c_void_p), ("wt", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
+        ("out", C.c_void_p), ("a_scale", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int32), ("ldw", C.c_int32), ("ldr", C.c_int32), ("ldc", C.c_int32),
+        ("out_f32", C.c_int32), ("act", C.c_int32), ("act_after_res", C.c_int32),
+        ("res_mod", C.c_int32),
+        ("remap_in", C.c_int32), ("remap_out", C.c_int32), ("remap_off", C.c_int32),
+        ("mode", C.c_int32),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32),
+        ("pad_t", C.c_int32), ("pad_l", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32),
+        ("rows_per_image", C.c_int32), ("tile_hint", C.c_int32),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("qkv", C.c_void_p), ("out", C.c_void_p), ("rel_bias", C.c_void_p),
+        ("batch", C.c_int32), ("n_tokens", C.c_int32), ("heads", C.c_int32), ("hd", C.c_int32),
+        ("scale", C.c_float),
+        ("window", C.c_int32), ("shift", C.c_int32), ("res_h", C.c_int32), ("res_w", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/tfimm_hip.h
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+SYMBOLS = {
+    "tfimm_hip_abi_version": (_i, []),
+    "tfimm_hip_last_error": (C.c_char_p, []),
+    "tfimm_hip_device_info": (_i, [_i, C.c_char_p, _i]),
+    "tfimm_hip_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
+    "tfimm_hip_cast_input": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp]),
+    "tfimm_hip_layernorm": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i64, _i64, _f, _vp]),
+    "tfimm_hip_attention": (_i, [C.POINTER(AttnDesc), _vp]),
+    "tfimm_hip_maxpool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "tfimm_hip_mean_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "tfimm_hip_bcast_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "tfimm_hip_dwconv": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "tfimm_hip_se_gate": (_i, [_vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "tfimm_hip_scale_channels": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tfimm_hip_patch_merge_ln": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "tfimm_hip_bias_act": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
+}
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C tensorflow-image-models_amd/csrc -j8` "
+            "(or __graft_entry__.build()). tfimm has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI drifted
+        fn.restype = res
+        fn.argtypes = args
+    if lib.tfimm_hip_abi_version() != 1:
+        raise ImportError("libtfimm_hip.so ABI version mismatch")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib.tfimm_hip_last_error().decode("utf-8", "replace")
+        raise HipError(f"{what or 'tfimm_hip call'} failed (rc={rc}): {msg}")

@@ -1,0 +1,15 @@
+from .cache import (  # noqa: F401
+    cached_model_path,
+    clear_model_cache,
+    get_dir,
+    list_cached_models,
+    set_dir,
+    set_model_cache,
+)
+from .constants import (  # noqa: F401
+    IMAGENET_DEFAULT_MEAN,
+    IMAGENET_DEFAULT_STD,
+    IMAGENET_INCEPTION_MEAN,
+    IMAGENET_INCEPTION_STD,
+)
+from .etc import get_padding, make_divisible, same_padding, to_2tuple  # noqa: F401
