@@ -82,7 +82,7 @@ TFIMM_API int tfimm_hip_device_info(int device, char* name, int len);
  *   PatchEmbeddings conv                   layers/transformers.py:164-165
  *   residual adds                          vit.py:228,234  resnet.py:289  efficientnet_blocks.py:451
  *
- * mode TFIMM_A_CONV:  m = (b*OH + oy)*OW + ox,  k = (ky*KW + kx)*Cin + ci,
+ * mode TFIMM_A_CONV:  m = (b*OH + oy)*OW + ox,  k = (ky*KW + kx)*Cin + ci  (Cin % 8 != 0 takes a slow element-load path),
  *     A[m][k] = x[b][oy*stride - pad_t + ky][ox*stride - pad_l + kx][ci]  (0 outside the image)
  * mode TFIMM_A_CONV_C4: Cin == 4, k = (ky*KWp + kx)*4 + ci with KWp = KW rounded up to even
  *     (the packed weight has zero columns for kx >= KW).

@@ -1,0 +1,158 @@
+"""CPU restatement of the TensorFlow/Keras 2.12 ops the tfimm forward path calls.
+
+TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import anything under oracle/.  The product path
+(tensorflow-image-models_amd/) never does and fails loudly without its HIP library.
+
+Parity status: TensorFlow is a third-party, un-vendored dependency of the reference
+(tensorflow 2.12.0, poetry.lock:1405-1406) and cannot be installed here, so these functions
+restate the published semantics of each op on top of torch-CPU fp32
+tensors, NHWC / HWIO layouts exactly as the reference uses them.  They are pinned by
+tests/test_oracle_ops.py against hand-computed known answers and independent numpy
+formulations; the model-level restatements in this package are additionally pinned by
+running the reference's OWN model code over these ops (oracle/tf_shim, see
+oracle/README.md).
+
+Every function cites the reference call sites it serves.
+"""
+import math
+from typing import Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+T = torch.Tensor
+
+
+def as_t(x) -> T:
+    if isinstance(x, torch.Tensor):
+        return x.float()
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=np.float32))
+
+
+# ---- padding ------------------------------------------------------------------------------
+def zero_pad2d(x: T, pad: Union[int, Tuple[int, int], Tuple[Tuple[int, int], Tuple[int, int]]]) -> T:
+    """tf.keras.layers.ZeroPadding2D on NHWC (resnet.py:229,505; layers/conv.py:80-88)."""
+    if isinstance(pad, int):
+        pt = pb = pl = pr = pad
+    elif isinstance(pad[0], int):
+        pt = pb = pad[0]
+        pl = pr = pad[1]
+    else:
+        (pt, pb), (pl, pr) = pad
+    return F.pad(x, (0, 0, pl, pr, pt, pb))
+
+
+def same_pad_amounts(size: int, k: int, s: int, d: int = 1) -> Tuple[int, int]:
+    """TF padding="same": out = ceil(in/s); total = max((out-1)*s + k_eff - in, 0);
+    before = total // 2, after = total - before."""
+    k_eff = (k - 1) * d + 1
+    out = -(-size // s)
+    total = max((out - 1) * s + k_eff - size, 0)
+    return total // 2, total - total // 2
+
+
+# ---- convolutions -----------------------------------------------------------------------------
+def conv2d(x: T, kernel: T, bias: Optional[T] = None, stride: int = 1, padding: str = "valid",
+           groups: int = 1) -> T:
+    """tf.keras.layers.Conv2D: NHWC input, HWIO kernel, cross-correlation
+    (vit/resnet/efficientnet conv call sites; transformers.py:155-163)."""
+    kh, kw = kernel.shape[0], kernel.shape[1]
+    if padding == "same":
+        pt, pb = same_pad_amounts(x.shape[1], kh, stride)
+        pl, pr = same_pad_amounts(x.shape[2], kw, stride)
+        x = zero_pad2d(x, ((pt, pb), (pl, pr)))
+    elif padding != "valid":
+        raise ValueError(padding)
+    w = kernel.permute(3, 2, 0, 1).contiguous()  # HWIO -> OIHW
+    y = F.conv2d(x.permute(0, 3, 1, 2), w, bias, stride=stride, groups=groups)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def depthwise_conv2d(x: T, kernel: T, bias: Optional[T] = None, stride: int = 1,
+                     padding: str = "valid") -> T:
+    """tf.keras.layers.DepthwiseConv2D: kernel (kh, kw, C, 1) (layers/conv.py:91-148)."""
+    kh, kw, c, mult = kernel.shape
+    assert mult == 1
+    if padding == "same":
+        pt, pb = same_pad_amounts(x.shape[1], kh, stride)
+        pl, pr = same_pad_amounts(x.shape[2], kw, stride)
+        x = zero_pad2d(x, ((pt, pb), (pl, pr)))
+    w = kernel.permute(2, 3, 0, 1).contiguous()  # (C, 1, kh, kw)
+    y = F.conv2d(x.permute(0, 3, 1, 2), w, bias, stride=stride, groups=c)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def dense(x: T, kernel: T, bias: Optional[T] = None) -> T:
+    """tf.keras.layers.Dense: x @ kernel (in, out) + bias on the last axis."""
+    y = x @ kernel
+    return y if bias is None else y + bias
+
+
+# ---- normalisation ------------------------------------------------------------------------------
+def layer_norm(x: T, gamma: T, beta: T, eps: float) -> T:
+    """Keras LayerNormalization, non-fused path (eps < 1.001e-5): two-pass population
+    moments over the last axis, y = x*inv + (beta - mean*inv), inv = rsqrt(var+eps)*gamma."""
+    mean = x.mean(dim=-1, keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=-1, keepdim=True)
+    inv = torch.rsqrt(var + eps) * gamma
+    return x * inv + (beta - mean * inv)
+
+
+def batch_norm(x: T, gamma: T, beta: T, mean: T, var: T, eps: float) -> T:
+    """Keras BatchNormalization at training=False: gamma*(x-mean)*rsqrt(var+eps)+beta."""
+    return (x - mean) * torch.rsqrt(var + eps) * gamma + beta
+
+
+# ---- activations (layers/factory.py:6-13) ---------------------------------------------------------
+def activation(x: T, name: str) -> T:
+    if name in ("linear", "", None):
+        return x
+    if name == "relu":
+        return torch.relu(x)
+    if name == "relu6":
+        return torch.clamp(x, 0.0, 6.0)
+    if name == "gelu":  # keras gelu(approximate=False): exact erf
+        return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+    if name == "swish":
+        return x * torch.sigmoid(x)
+    if name == "sigmoid":
+        return torch.sigmoid(x)
+    if name == "tanh":
+        return torch.tanh(x)
+    raise ValueError(f"Unknown activation: {name}.")
+
+
+def softmax(x: T, axis: int = -1) -> T:
+    return torch.softmax(x, dim=axis)
+
+
+# ---- pooling ----------------------------------------------------------------------------------------
+def max_pool2d(x: T, k: int, stride: int) -> T:
+    """tf.keras.layers.MaxPool2D(pool_size=k, strides=stride), VALID, NHWC (resnet.py:539)."""
+    y = F.max_pool2d(x.permute(0, 3, 1, 2), k, stride)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def avg_pool2d_same(x: T, k: int, stride: int) -> T:
+    """AveragePooling2D(padding="same"): windows are clipped at the border and the average
+    is taken over the VALID elements only (resnet.py:299-301, downsample_avg)."""
+    pt, pb = same_pad_amounts(x.shape[1], k, stride)
+    pl, pr = same_pad_amounts(x.shape[2], k, stride)
+    xp = F.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb))
+    ones = F.pad(torch.ones_like(x[..., :1]).permute(0, 3, 1, 2), (pl, pr, pt, pb))
+    s = F.avg_pool2d(xp, k, stride) * (k * k)
+    n = F.avg_pool2d(ones, k, stride) * (k * k)
+    return (s / n).permute(0, 2, 3, 1).contiguous()
+
+
+def global_avg_pool(x: T) -> T:
+    """GlobalAveragePooling2D (NHWC -> NC) / GlobalAveragePooling1D (NLC -> NC)."""
+    return x.mean(dim=tuple(range(1, x.dim() - 1)))
+
+
+# ---- tensor shuffles --------------------------------------------------------------------------------
+def roll(x: T, shift: Sequence[int], axis: Sequence[int]) -> T:
+    """tf.roll: out[i] = in[(i - shift) mod n]  (swin.py:299,313)."""
+    return torch.roll(x, shifts=tuple(shift), dims=tuple(axis))

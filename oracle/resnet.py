@@ -1,0 +1,103 @@
+"""fp32 CPU restatement of reference tfimm/architectures/resnet.py (test infrastructure).
+
+Follows ResNet.forward_features / call (resnet.py:570-593), BasicBlock.call (:166-189),
+Bottleneck.call (:266-292), downsample_conv / downsample_avg (:295-330), make_stage
+(:333-382), SEModule.call (layers/attention.py:66-74) and ClassifierHead.call
+(layers/classifier.py:65-74).  Convs and BNs are kept as separate steps, as in the reference.
+"""
+import math
+from collections import OrderedDict
+
+from . import ops
+from .common import BN_EPS, W, finish
+
+
+def _se(w: W, x, prefix):
+    # layers/attention.py:66-74 (bn = identity, act = relu, gate = sigmoid)
+    s = x.mean(dim=(1, 2), keepdim=True)
+    s = ops.conv2d(s, w(prefix + "/fc1/kernel"), w(prefix + "/fc1/bias"))
+    s = ops.activation(s, "relu")
+    s = ops.conv2d(s, w(prefix + "/fc2/kernel"), w(prefix + "/fc2/bias"))
+    return x * ops.activation(s, "sigmoid")
+
+
+def _downsample(w: W, cfg, x, prefix, stride, eps):
+    if cfg.downsample_mode == "avg":                                   # resnet.py:295-312
+        if stride != 1:
+            x = ops.avg_pool2d_same(x, 2, stride)
+        x = ops.conv2d(x, w(prefix + "/downsample/1/kernel"))
+        return w.bn(x, prefix + "/downsample/2", eps)
+    p = (stride + cfg.down_kernel_size) // 2 - 1                       # resnet.py:319
+    x = ops.zero_pad2d(x, p)
+    x = ops.conv2d(x, w(prefix + "/downsample/0/kernel"), stride=stride)
+    return w.bn(x, prefix + "/downsample/1", eps)
+
+
+def resnet_forward(cfg, weights, x, return_features=False):
+    assert not cfg.aa_layer and cfg.cardinality == 1 and cfg.attn_layer in ("", "se")
+    w = W(weights)
+    eps = BN_EPS[cfg.norm_layer]
+    act = cfg.act_layer
+    x = ops.as_t(x)
+    feats = OrderedDict()
+    # ---- stem (resnet.py:572-576)
+    if cfg.stem_type in ("deep", "deep_tiered"):
+        x = ops.zero_pad2d(x, 1)                                        # pad1
+        x = ops.conv2d(x, w("conv1/0/kernel"), stride=2)
+        x = ops.activation(w.bn(x, "conv1/1", eps), act)
+        x = ops.conv2d(x, w("conv1/3/kernel"), padding="same")
+        x = ops.activation(w.bn(x, "conv1/4", eps), act)
+        x = ops.conv2d(x, w("conv1/6/kernel"), padding="same")
+    else:
+        x = ops.zero_pad2d(x, 3)
+        x = ops.conv2d(x, w("conv1/kernel"), stride=2)
+    x = ops.activation(w.bn(x, "bn1", eps), act)
+    if cfg.replace_stem_pool:                                           # resnet.py:517-530
+        x = ops.zero_pad2d(x, 1)
+        x = ops.conv2d(x, w("maxpool/0/kernel"), stride=2)
+        x = ops.activation(w.bn(x, "maxpool/1", eps), act)
+    else:                                                               # resnet.py:537-540
+        x = ops.max_pool2d(ops.zero_pad2d(x, 1), 3, 2)
+    feats["stem"] = x
+    # ---- stages (make_stage, resnet.py:333-382)
+    expansion = 1 if cfg.block == "basic_block" else 4
+    in_channels = cfg.stem_width * 2 if cfg.stem_type in ("deep", "deep_tiered") else 64
+    j = 0
+    for idx in range(4):
+        nb_channels = cfg.nb_channels[idx]
+        out_channels = nb_channels * expansion
+        for block_idx in range(cfg.nb_blocks[idx]):
+            stride = 1 if idx == 0 or block_idx > 0 else 2
+            p = f"layer{idx + 1}/{block_idx}"
+            has_down = block_idx == 0 and (stride != 1 or in_channels != out_channels)
+            shortcut = x
+            if cfg.block == "basic_block":                              # BasicBlock.call
+                y = ops.zero_pad2d(x, 1)
+                y = ops.conv2d(y, w(p + "/conv1/kernel"), stride=stride)
+                y = ops.activation(w.bn(y, p + "/bn1", eps), act)
+                y = ops.zero_pad2d(y, 1)
+                y = ops.conv2d(y, w(p + "/conv2/kernel"))
+                y = w.bn(y, p + "/bn2", eps)
+            else:                                                       # Bottleneck.call
+                y = ops.conv2d(x, w(p + "/conv1/kernel"))
+                y = ops.activation(w.bn(y, p + "/bn1", eps), act)
+                y = ops.zero_pad2d(y, 1)
+                y = ops.conv2d(y, w(p + "/conv2/kernel"), stride=stride)
+                y = ops.activation(w.bn(y, p + "/bn2", eps), act)
+                y = ops.conv2d(y, w(p + "/conv3/kernel"))
+                y = w.bn(y, p + "/bn3", eps)
+            if cfg.attn_layer == "se":
+                y = _se(w, y, p + "/se")
+            if has_down:
+                shortcut = _downsample(w, cfg, shortcut, p, stride, eps)
+            x = ops.activation(y + shortcut, act)
+            feats[f"block_{j}"] = x
+            j += 1
+            in_channels = nb_channels                                   # resnet.py:380
+    feats["features"] = x
+    # ---- head: GAP -> fc -> flatten (layers/classifier.py:65-74)
+    x = ops.global_avg_pool(x)
+    if cfg.nb_classes > 0:
+        x = w.dense(x, "remove/fc")
+    feats["logits"] = x
+    return finish(x, feats, return_features)

@@ -35,7 +35,7 @@ int num_cu() {
 
 // tile ids: 0 128x128, 1 128x64, 2 64x64, 3 256x128, 4 128x256, 5 64x128
 int pick_tile(const tfimm_gemm_desc& d, int kmode) {
-  if (kmode == K_DENSE_SCALAR) return 2;
+  if (kmode == K_DENSE_SCALAR || kmode == K_CONV_SCALAR) return 2;
   if (d.tile_hint > 0 && d.tile_hint <= TFIMM_GEMM_NUM_TILES && tile_table(d.tile_hint - 1)->fn[kmode])
     return d.tile_hint - 1;
   const int cus = num_cu();
@@ -93,9 +93,8 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
     if ((int64_t)d.B * d.OH * d.OW != d.M) TFIMM_FAIL(TFIMM_EINVAL, "gemm: M != B*OH*OW");
     if (((uintptr_t)d.a & 15)) TFIMM_FAIL(TFIMM_EINVAL, "gemm: conv input must be 16-byte aligned");
     if (d.mode == TFIMM_A_CONV) {
-      if (d.Cin & 7) TFIMM_FAIL(TFIMM_EINVAL, "gemm: conv mode needs Cin %% 8 == 0 (Cin=%d)", d.Cin);
       if (d.K != d.KH * d.KW * d.Cin) TFIMM_FAIL(TFIMM_EINVAL, "gemm: K != KH*KW*Cin");
-      kmode = K_CONV;
+      kmode = (d.Cin & 7) ? K_CONV_SCALAR : K_CONV;  // odd channel counts: element loads
     } else {
       if (d.Cin != 4) TFIMM_FAIL(TFIMM_EINVAL, "gemm: C4 mode needs Cin == 4");
       if (d.K != d.KH * g.KWp * 4) TFIMM_FAIL(TFIMM_EINVAL, "gemm: K != KH*KWp*4 (K=%d)", d.K);

@@ -36,6 +36,7 @@ struct Pick<KM, false> {
 extern "C" __attribute__((visibility("hidden"))) const TileCfg TFIMM_CAT(tfimm_gemm_tile_, TILE_ID) = {
     T::bm, T::bn, T::wm* T::wn * 64,
     {Pick<K_DENSE, true>::fn, Pick<K_CONV, true>::fn, Pick<K_CONV_C4, true>::fn,
-     Pick<K_DENSE_SCALAR, kHasScalar>::fn, Pick<K_DENSE_SCALE, kHasScale>::fn}};
+     Pick<K_DENSE_SCALAR, kHasScalar>::fn, Pick<K_DENSE_SCALE, kHasScale>::fn,
+     Pick<K_CONV_SCALAR, kHasScalar>::fn}};
 
 }  // namespace tfimm_gemm

@@ -36,7 +36,8 @@ enum {
   K_CONV_C4 = 2,       // NHWC gather, Cin == 4
   K_DENSE_SCALAR = 3,  // dense rows, arbitrary K / lda / alignment (element loads)
   K_DENSE_SCALE = 4,   // dense rows * per-(image, k) SE gate
-  K_NUM = 5
+  K_CONV_SCALAR = 5,   // NHWC gather, arbitrary Cin (element loads; odd-shaped test models)
+  K_NUM = 6
 };
 
 struct GemmArgs {
@@ -139,6 +140,8 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_kernel(const GemmA
     *ok1 = false;
     if (DENSE) {
       return a_ok[i] && (kt * BK + lc * 8) < p.K;
+    } else if (KMODE == K_CONV_SCALAR) {
+      return a_ok[i];
     } else if (KMODE == K_CONV) {
       const int kg = kt * BK + lc * 8;
       const int tap = kg / p.Cin;
@@ -194,6 +197,25 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_kernel(const GemmA
         const size_t off = ok ? ((size_t)(a_pix[i] + iy * p.W + ix)) * p.Cin + ci : (size_t)0;
         ra[i] = *reinterpret_cast<const uint4*>(p.a + off);
       }
+    } else if (KMODE == K_CONV_SCALAR) {
+#pragma unroll
+      for (int i = 0; i < A_ITERS; ++i) {
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = kg + e;
+          const int tap = k / p.Cin;
+          const int ci = k - tap * p.Cin;
+          const int ky = tap / p.KW, kx = tap - ky * p.KW;
+          const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+          const bool ok = k < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+          const size_t off = ok ? ((size_t)(a_pix[i] + iy * p.W + ix)) * p.Cin + ci : (size_t)0;
+          uint32_t v = (uint32_t)p.a[off];
+          v = ok ? v : 0u;
+          w[e >> 1] |= v << ((e & 1) * 16);
+        }
+        ra[i] = make_uint4(w[0], w[1], w[2], w[3]);
+      }
     } else {  // K_CONV_C4: chunk = two adjacent 4-channel pixels of one filter row
 #pragma unroll
       for (int i = 0; i < A_ITERS; ++i) {
@@ -223,8 +245,8 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_kernel(const GemmA
       uint4 v = ra[i];
       if (KMODE == K_CONV_C4) {
         v = make_uint4(ok0 ? v.x : 0u, ok0 ? v.y : 0u, ok1 ? v.z : 0u, ok1 ? v.w : 0u);
-      } else if (KMODE == K_DENSE_SCALAR) {
-        v = sel4(a_ok[i], v);  // per-element k masking already applied at load
+      } else if (KMODE == K_DENSE_SCALAR || KMODE == K_CONV_SCALAR) {
+        v = sel4(a_ok[i], v);  // per-element masking already applied at load
       } else {
         v = sel4(ok0, v);
       }

@@ -1,0 +1,329 @@
+"""ResNet family on the MI355X engine.
+
+Behavioural mirror of reference tfimm/architectures/resnet.py (ResNetConfig :55-99,
+BasicBlock :102-189, Bottleneck :192-292, downsample_avg/_conv :295-330, make_stage
+:333-382, ResNet :385-593, registrations :596-1705).  Lowering:
+
+  every Conv2D(+ZeroPadding2D) + BatchNormalization(inference) + ReLU group is ONE
+  implicit-GEMM kernel launch with the BN folded into the packed weights and the ReLU in
+  the epilogue; the block's shortcut add + final ReLU ride in the epilogue of its last conv
+  (resnet.py:266-292); the 7x7 stem reads the padded-RGB image directly (no im2col).
+
+Not built (raise NotImplementedError at lowering): grouped 3x3 convs (ResNeXt), ECA,
+BlurPool anti-aliasing, GroupNorm.
+"""
+import math
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+from ..models.config import ModelConfig
+from ..models.model import Model, WeightSpec
+from ..models.registry import register_model
+from ..utils.constants import IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD
+from ..utils.etc import make_divisible
+
+__all__ = ["ResNet", "ResNetConfig"]
+
+_BN_EPS = {"batch_norm": 1e-5, "batch_norm_tf": 1e-3}  # layers/factory.py:22-37
+
+
+@dataclass
+class ResNetConfig(ModelConfig):
+    nb_classes: int = 1000
+    in_channels: int = 3
+    input_size: Tuple[int, int] = (224, 224)
+    # Residual blocks
+    block: str = "basic_block"
+    nb_blocks: Tuple = (2, 2, 2, 2)
+    nb_channels: Tuple = (64, 128, 256, 512)
+    cardinality: int = 1
+    base_width: int = 64
+    downsample_mode: str = "conv"
+    zero_init_last_bn: bool = True
+    # Stem
+    stem_width: int = 64
+    stem_type: str = ""
+    replace_stem_pool: bool = False
+    # Other params
+    block_reduce_first: int = 1
+    down_kernel_size: int = 1
+    act_layer: str = "relu"
+    norm_layer: str = "batch_norm"
+    aa_layer: str = ""
+    attn_layer: str = ""
+    se_ratio: float = 0.0625
+    # Regularization
+    drop_rate: float = 0.0
+    drop_path_rate: float = 0.0
+    # Head
+    global_pool: str = "avg"
+    # Parameters for inference
+    test_input_size: Optional[Tuple[int, int]] = None
+    pool_size: int = 7
+    crop_pct: float = 0.875
+    interpolation: str = "bilinear"
+    # Preprocessing
+    mean: Tuple[float, float, float] = IMAGENET_DEFAULT_MEAN
+    std: Tuple[float, float, float] = IMAGENET_DEFAULT_STD
+    # Weight transfer
+    first_conv: str = "conv1"
+    classifier: str = "fc"
+
+    def __post_init__(self):
+        if self.test_input_size is None:
+            self.test_input_size = self.input_size
+
+
+def _bn_specs(s, prefix, c, zero_init=False):
+    z = "zeros" if zero_init else ""
+    s[prefix + "/gamma"] = WeightSpec((c,), "gamma", z)
+    s[prefix + "/beta"] = WeightSpec((c,), "beta")
+    s[prefix + "/moving_mean"] = WeightSpec((c,), "mean")
+    s[prefix + "/moving_variance"] = WeightSpec((c,), "var", z)
+
+
+class ResNet(Model):
+    cfg_class = ResNetConfig
+    keys_to_ignore_on_load = ("blur_kernel",)
+
+    # ---- architecture walk shared by weight_specs() and lower() -----------------------------------
+    def _stages(self):
+        """Yields (stage idx, block idx, in_ch, nb_channels, out_ch, stride, has_downsample)."""
+        c = self.cfg
+        expansion = 1 if c.block == "basic_block" else 4
+        in_ch = c.stem_width * 2 if c.stem_type in ("deep", "deep_tiered") else 64
+        for idx in range(4):
+            nb_ch = c.nb_channels[idx]
+            out_ch = nb_ch * expansion
+            for bidx in range(c.nb_blocks[idx]):
+                stride = 1 if idx == 0 or bidx > 0 else 2
+                down = bidx == 0 and (stride != 1 or in_ch != out_ch)
+                yield idx, bidx, in_ch, nb_ch, out_ch, stride, down
+                # NOTE: the reference sets in_channels = nb_channels (not out_channels) after
+                # each block (resnet.py:380); only the block-0 test uses it, and for Bottleneck
+                # nets nb_channels != out_channels so later stages always get a downsample
+                # layer, exactly as here.
+                in_ch = nb_ch
+            in_ch = nb_ch
+
+    def _block_widths(self, nb_ch):
+        c = self.cfg
+        if c.block == "basic_block":
+            first = nb_ch // c.block_reduce_first
+            return first, nb_ch, nb_ch
+        width = int(math.floor(nb_ch * (c.base_width / 64)) * c.cardinality)   # resnet.py:213
+        return width // c.block_reduce_first, width, nb_ch * 4
+
+    def weight_specs(self):
+        c = self.cfg
+        s = OrderedDict()
+        if c.stem_type in ("deep", "deep_tiered"):
+            ch = (3 * (c.stem_width // 4), c.stem_width) if c.stem_type == "deep_tiered" else (c.stem_width, c.stem_width)
+            s["conv1/0/kernel"] = WeightSpec((3, 3, c.in_channels, ch[0]), "conv")
+            _bn_specs(s, "conv1/1", ch[0])
+            s["conv1/3/kernel"] = WeightSpec((3, 3, ch[0], ch[1]), "conv")
+            _bn_specs(s, "conv1/4", ch[1])
+            s["conv1/6/kernel"] = WeightSpec((3, 3, ch[1], c.stem_width * 2), "conv")
+            stem_out = c.stem_width * 2
+        else:
+            s["conv1/kernel"] = WeightSpec((7, 7, c.in_channels, 64), "conv")
+            stem_out = 64
+        _bn_specs(s, "bn1", stem_out)
+        if c.replace_stem_pool:
+            s["maxpool/0/kernel"] = WeightSpec((3, 3, stem_out, stem_out), "conv")
+            _bn_specs(s, "maxpool/1", stem_out)
+        prev_out = stem_out
+        for idx, bidx, in_ch, nb_ch, out_ch, stride, down in self._stages():
+            p = f"layer{idx + 1}/{bidx}"
+            first, width, outp = self._block_widths(nb_ch)
+            zi = c.zero_init_last_bn
+            if c.block == "basic_block":
+                s[p + "/conv1/kernel"] = WeightSpec((3, 3, prev_out, first), "conv")
+                _bn_specs(s, p + "/bn1", first)
+                s[p + "/conv2/kernel"] = WeightSpec((3, 3, first, outp), "conv")
+                _bn_specs(s, p + "/bn2", outp, zero_init=zi)
+            else:
+                s[p + "/conv1/kernel"] = WeightSpec((1, 1, prev_out, first), "conv")
+                _bn_specs(s, p + "/bn1", first)
+                s[p + "/conv2/kernel"] = WeightSpec((3, 3, first // c.cardinality, width), "conv")
+                _bn_specs(s, p + "/bn2", width)
+                s[p + "/conv3/kernel"] = WeightSpec((1, 1, width, outp), "conv")
+                _bn_specs(s, p + "/bn3", outp, zero_init=zi)
+            if c.attn_layer == "se":
+                rd = make_divisible(outp * c.se_ratio, 8, round_limit=0.0)     # layers/attention.py:50-52
+                s[p + "/se/fc1/kernel"] = WeightSpec((1, 1, outp, rd), "conv")
+                s[p + "/se/fc1/bias"] = WeightSpec((rd,), "bias")
+                s[p + "/se/fc2/kernel"] = WeightSpec((1, 1, rd, outp), "conv")
+                s[p + "/se/fc2/bias"] = WeightSpec((outp,), "bias")
+            elif c.attn_layer == "eca":
+                t = int(abs(math.log(outp, 2) + 1) / 2)                          # layers/attention.py:104-106
+                k = max(t if t % 2 else t + 1, 3)
+                s[p + "/se/conv/kernel"] = WeightSpec((k, 1, 1), "conv")
+            if down:
+                if c.downsample_mode == "avg":
+                    s[p + "/downsample/1/kernel"] = WeightSpec((1, 1, prev_out, out_ch), "conv")
+                    _bn_specs(s, p + "/downsample/2", out_ch)
+                else:
+                    k = c.down_kernel_size
+                    s[p + "/downsample/0/kernel"] = WeightSpec((k, k, prev_out, out_ch), "conv")
+                    _bn_specs(s, p + "/downsample/1", out_ch)
+            prev_out = out_ch
+        if c.nb_classes > 0:
+            s["remove/fc/kernel"] = WeightSpec((prev_out, c.nb_classes), "dense")
+            s["remove/fc/bias"] = WeightSpec((c.nb_classes,), "bias")
+        self.nb_features = prev_out
+        return s
+
+    @property
+    def feature_names(self) -> List[str]:
+        return ["stem"] + [f"block_{j}" for j in range(sum(self.cfg.nb_blocks))] + ["features", "logits"]
+
+    # ---- lowering ---------------------------------------------------------------------------------------
+    def lower(self, b, H, W, want_features):
+        c = self.cfg
+        if c.norm_layer not in _BN_EPS:
+            raise NotImplementedError(f"norm_layer={c.norm_layer!r} is outside this engine's scope (GroupNorm).")
+        if c.aa_layer:
+            raise NotImplementedError("BlurPool2D anti-aliasing (aa_layer) is not built.")
+        if c.cardinality != 1:
+            raise NotImplementedError("grouped 3x3 convolutions (ResNeXt cardinality > 1) are not built yet.")
+        if c.attn_layer not in ("", "se"):
+            raise NotImplementedError(f"attn_layer={c.attn_layer!r} is not built yet.")
+        if c.global_pool != "avg":
+            raise NotImplementedError("only global_pool='avg' is built.")
+        eps = _BN_EPS[c.norm_layer]
+        act = c.act_layer
+        x = b.image_input(H, W, c.in_channels)
+        # ---- stem (resnet.py:466-512, 572-575)
+        if c.stem_type in ("deep", "deep_tiered"):
+            x = b.conv(x, "conv1/0/kernel", stride=2, padding=1, bn="conv1/1", bn_eps=eps, act=act, cite="resnet.py:473-481")
+            x = b.conv(x, "conv1/3/kernel", padding="same", bn="conv1/4", bn_eps=eps, act=act, cite="resnet.py:482-490")
+            x = b.conv(x, "conv1/6/kernel", padding="same", bn="bn1", bn_eps=eps, act=act, cite="resnet.py:491-500,513-514")
+        else:
+            x = b.conv(x, "conv1/kernel", stride=2, padding=3, bn="bn1", bn_eps=eps, act=act, cite="resnet.py:505-514")
+        # ---- stem pooling (resnet.py:517-540)
+        if c.replace_stem_pool:
+            x = b.conv(x, "maxpool/0/kernel", stride=2, padding=1, bn="maxpool/1", bn_eps=eps, act=act, cite="resnet.py:520-530")
+        else:
+            x = b.maxpool(x, 3, 2, 1, cite="resnet.py:538-540")
+        if want_features:
+            b.p.mark_output("stem", x)
+        # ---- residual stages
+        j = 0
+        for idx, bidx, in_ch, nb_ch, out_ch, stride, down in self._stages():
+            p = f"layer{idx + 1}/{bidx}"
+            shortcut = x
+            if down:
+                if c.downsample_mode == "avg":
+                    raise NotImplementedError("downsample_mode='avg' (AveragePooling2D shortcut) is not built yet.")
+                pd = (stride + c.down_kernel_size) // 2 - 1                       # resnet.py:319
+                shortcut = b.conv(x, p + "/downsample/0/kernel", stride=stride, padding=pd, bn=p + "/downsample/1",
+                                  bn_eps=eps, cite="resnet.py:315-330")
+            se = c.attn_layer == "se"
+            last = dict(residual=None if se else shortcut, act="" if se else act, act_after_res=not se)
+            if c.block == "basic_block":
+                y = b.conv(x, p + "/conv1/kernel", stride=stride, padding=1, bn=p + "/bn1", bn_eps=eps, act=act,
+                           cite="resnet.py:168-172")
+                y = b.conv(y, p + "/conv2/kernel", padding=1, bn=p + "/bn2", bn_eps=eps, cite="resnet.py:176-186", **last)
+            else:
+                y = b.conv(x, p + "/conv1/kernel", bn=p + "/bn1", bn_eps=eps, act=act, cite="resnet.py:269-271")
+                y = b.conv(y, p + "/conv2/kernel", stride=stride, padding=1, bn=p + "/bn2", bn_eps=eps, act=act,
+                           cite="resnet.py:273-276")
+                y = b.conv(y, p + "/conv3/kernel", bn=p + "/bn3", bn_eps=eps, cite="resnet.py:280-290", **last)
+            if se:
+                m = b.mean_rows(y, out_f32=True, cite="layers/attention.py:67")
+                g = b.se_gate(m, 1, p + "/se/fc1/kernel", p + "/se/fc1/bias", p + "/se/fc2/kernel", p + "/se/fc2/bias",
+                              act="relu", cite="layers/attention.py:68-72")
+                y = b.scale_channels(y, g, residual=shortcut, relu_after=True, cite="layers/attention.py:73 + resnet.py:289-290")
+            x = y
+            if want_features:
+                b.p.mark_output(f"block_{j}", x)
+            j += 1
+        b.p.mark_output("features", x)
+        # ---- head (layers/classifier.py:65-74)
+        pooled = b.mean_rows(x, cite="layers/classifier.py:66-67")
+        if c.nb_classes > 0:
+            logits = b.dense(pooled, "remove/fc/kernel", "remove/fc/bias", out_f32=True, cite="layers/classifier.py:70-71")
+        else:
+            logits = pooled
+        b.p.mark_output("logits", logits)
+
+
+# ---------------------------------------------------------------------------------------
+# registrations (reference resnet.py:596-1705)
+# ---------------------------------------------------------------------------------------
+_D = dict(stem_width=32, stem_type="deep", downsample_mode="avg", first_conv="conv1/0")
+_T = dict(stem_width=32, stem_type="deep_tiered", downsample_mode="avg", first_conv="conv1/0")
+_BC = dict(interpolation="bicubic")
+_L = {18: ("basic_block", (2, 2, 2, 2)), 26: ("bottleneck", (2, 2, 2, 2)), 34: ("basic_block", (3, 4, 6, 3)),
+      50: ("bottleneck", (3, 4, 6, 3)), 101: ("bottleneck", (3, 4, 23, 3)), 152: ("bottleneck", (3, 8, 36, 3)),
+      200: ("bottleneck", (3, 24, 36, 3))}
+
+
+def _rn(name, depth, **kw):
+    block, blocks = _L[depth]
+    return ResNetConfig(**{**dict(name=name, url="[timm]", block=block, nb_blocks=blocks), **kw})
+
+
+def _x(card, width):
+    return dict(cardinality=card, base_width=width)
+
+
+def _rs(name, blocks, res, test, pool, crop):
+    return ResNetConfig(name=name, url="[timm]", block="bottleneck", nb_blocks=blocks, input_size=(res, res),
+                        test_input_size=(test, test), pool_size=pool, crop_pct=crop, attn_layer="se", se_ratio=0.25,
+                        replace_stem_pool=True, **_D, **_BC)
+
+
+def _register(cfg):
+    def fn():
+        return ResNet, cfg
+    fn.__name__ = fn.__qualname__ = cfg.name
+    fn.__module__ = __name__
+    fn.__doc__ = f"{cfg.name} (reference tfimm/architectures/resnet.py)"
+    globals()[cfg.name] = register_model(fn)
+
+
+_BIG = dict(input_size=(256, 256), test_input_size=(320, 320), pool_size=8, crop_pct=1.0)
+for _cfg in [
+    _rn("resnet18", 18), _rn("resnet18d", 18, **_D, **_BC), _rn("resnet34", 34), _rn("resnet34d", 34, **_D, **_BC),
+    _rn("resnet26", 26, **_BC), _rn("resnet26d", 26, **_D, **_BC),
+    _rn("resnet26t", 26, input_size=(256, 256), pool_size=8, crop_pct=0.94, **_T, **_BC),
+    _rn("resnet50", 50, crop_pct=0.95, **_BC), _rn("resnet50d", 50, **_D, **_BC),
+    _rn("resnet101", 101, crop_pct=0.95, **_BC), _rn("resnet101d", 101, **_D, **_BC, **_BIG),
+    _rn("resnet152", 152, crop_pct=0.95, **_BC), _rn("resnet152d", 152, **_D, **_BC, **_BIG),
+    _rn("resnet200d", 200, **_D, **_BC, **_BIG),
+    _rn("tv_resnet34", 34), _rn("tv_resnet50", 50), _rn("tv_resnet101", 101), _rn("tv_resnet152", 152),
+    _rn("wide_resnet50_2", 50, base_width=128, **_BC), _rn("wide_resnet101_2", 101, base_width=128),
+    _rn("resnet50_gn", 50, crop_pct=0.94, norm_layer="group_norm", **_BC),
+    _rn("resnext50_32x4d", 50, crop_pct=0.95, **_x(32, 4), **_BC), _rn("resnext50d_32x4d", 50, **_x(32, 4), **_D, **_BC),
+    _rn("resnext101_32x8d", 101, **_x(32, 8)), _rn("tv_resnext50_32x4d", 50, **_x(32, 4)),
+    _rn("ig_resnext101_32x8d", 101, **_x(32, 8)), _rn("ig_resnext101_32x16d", 101, **_x(32, 16)),
+    _rn("ig_resnext101_32x32d", 101, **_x(32, 32)), _rn("ig_resnext101_32x48d", 101, **_x(32, 48)),
+    _rn("ssl_resnet18", 18), _rn("ssl_resnet50", 50), _rn("ssl_resnext50_32x4d", 50, **_x(32, 4)),
+    _rn("ssl_resnext101_32x4d", 101, **_x(32, 4)), _rn("ssl_resnext101_32x8d", 101, **_x(32, 8)),
+    _rn("ssl_resnext101_32x16d", 101, **_x(32, 16)),
+    _rn("swsl_resnet18", 18), _rn("swsl_resnet50", 50), _rn("swsl_resnext50_32x4d", 50, **_x(32, 4)),
+    _rn("swsl_resnext101_32x4d", 101, **_x(32, 4)), _rn("swsl_resnext101_32x8d", 101, **_x(32, 8)),
+    _rn("swsl_resnext101_32x16d", 101, **_x(32, 16)),
+    _rn("ecaresnet26t", 26, attn_layer="eca", input_size=(256, 256), test_input_size=(320, 320), pool_size=8,
+        crop_pct=0.95, **_T, **_BC),
+    _rn("ecaresnetlight", 50, nb_blocks=(1, 1, 11, 3), attn_layer="eca", stem_width=32, downsample_mode="avg", **_BC),
+    _rn("ecaresnet50d", 50, attn_layer="eca", **_D, **_BC),
+    _rn("ecaresnet50t", 50, attn_layer="eca", test_input_size=(320, 320), pool_size=8, crop_pct=0.95, **_T, **_BC),
+    _rn("ecaresnet101d", 101, attn_layer="eca", **_D, **_BC),
+    _rn("ecaresnet269d", 50, nb_blocks=(3, 30, 48, 8), attn_layer="eca", input_size=(320, 320),
+        test_input_size=(352, 352), pool_size=10, crop_pct=1.0, **_D, **_BC),
+    _rn("resnetblur50", 50, aa_layer="blur_pool", **_BC),
+    _rn("seresnet50", 50, attn_layer="se", **_BC), _rn("seresnet152d", 152, attn_layer="se", **_D, **_BC, **_BIG),
+    _rn("seresnext26d_32x4d", 26, attn_layer="se", **_x(32, 4), **_D, **_BC),
+    _rn("seresnext26t_32x4d", 26, attn_layer="se", **_x(32, 4), **_T, **_BC),
+    _rn("seresnext50_32x4d", 50, attn_layer="se", **_x(32, 4), **_BC),
+    _rs("resnetrs50", (3, 4, 6, 3), 160, 224, 5, 0.91), _rs("resnetrs101", (3, 4, 23, 3), 192, 288, 6, 0.94),
+    _rs("resnetrs152", (3, 8, 36, 3), 256, 320, 8, 1.0), _rs("resnetrs200", (3, 24, 36, 3), 256, 320, 8, 1.0),
+    _rs("resnetrs270", (4, 29, 53, 4), 256, 352, 8, 1.0), _rs("resnetrs350", (4, 36, 72, 4), 288, 384, 9, 1.0),
+    _rs("resnetrs420", (4, 44, 87, 4), 320, 416, 10, 1.0),
+]:
+    _register(_cfg)
+del _cfg

@@ -1,0 +1,668 @@
+"""Layer-program builder and executor.
+
+A model's ``lower()`` method traces its forward pass into a flat list of fused-kernel
+invocations (a *program*) using :class:`Builder`; each builder method corresponds to one
+C-ABI call of libtfimm_hip.so and cites the reference op sequence it fuses.  The program is
+pure host data (shapes, packed numpy weights) until :meth:`Program.upload`; a
+:class:`Plan` binds it to device buffers for one batch size and runs it by calling the C
+ABI through ctypes -- there is no other execution path.
+
+Activations are bf16 ``[B * rows_per_image, C]`` row-major (NHWC flattened); a tensor may
+carry its spatial extent ``(H, W)``.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from ..utils.etc import same_padding
+from . import pack
+
+
+# ---------------------------------------------------------------------------------------
+# symbolic tensors / constants
+# ---------------------------------------------------------------------------------------
+@dataclass
+class TRef:
+    """Activation tensor of the program: per-image ``rows x C`` (x batch at run time)."""
+    id: int
+    rows: int              # rows per image (H*W, tokens, or 1)
+    C: int
+    H: int = 0
+    W: int = 0
+    dtype: str = "bf16"    # "bf16" | "f32"
+    keep: bool = False     # never recycle the buffer (outputs / returned features)
+    # a view onto another tensor's buffer: (parent id, element offset per image-row stride)
+    name: str = ""
+
+    @property
+    def itemsize(self) -> int:
+        return 2 if self.dtype == "bf16" else 4
+
+    @property
+    def bytes_per_image(self) -> int:
+        return self.rows * self.C * self.itemsize
+
+
+@dataclass
+class Const:
+    """Device constant (packed weight).  ``host`` is a numpy array: uint16 = bf16 bits."""
+    id: int
+    host: np.ndarray
+    name: str = ""
+
+
+@dataclass
+class Op:
+    kind: str
+    inputs: List[int]            # TRef ids read
+    output: Optional[int]        # TRef id written
+    consts: Dict[str, int]       # role -> Const id
+    attrs: Dict[str, object]
+    cite: str = ""               # reference file:line this op replaces
+    extra_outputs: List[int] = field(default_factory=list)  # further tensors the kernel writes
+
+
+class Program:
+    def __init__(self):
+        self.tensors: List[TRef] = []
+        self.consts: List[Const] = []
+        self.ops: List[Op] = []
+        self.input: Optional[TRef] = None       # raw image tensor as handed in by the caller
+        self.input_shape: Tuple[int, int, int] = (0, 0, 0)
+        self.outputs: Dict[str, TRef] = {}
+        self._dev_consts = None
+        self._dev_consts_device = None
+
+    # -- construction helpers -------------------------------------------------------------
+    def new_tensor(self, rows, C, H=0, W=0, dtype="bf16", name="") -> TRef:
+        t = TRef(len(self.tensors), int(rows), int(C), int(H), int(W), dtype, False, name)
+        self.tensors.append(t)
+        return t
+
+    def new_const(self, host: np.ndarray, name="") -> int:
+        c = Const(len(self.consts), np.ascontiguousarray(host), name)
+        self.consts.append(c)
+        return c.id
+
+    def add(self, kind, inputs, output, consts=None, cite="", extra_outputs=(), **attrs) -> Op:
+        op = Op(kind, [t.id for t in inputs], None if output is None else output.id,
+                consts or {}, attrs, cite, [t.id for t in extra_outputs])
+        self.ops.append(op)
+        return op
+
+    def mark_output(self, name: str, t: TRef):
+        self.tensors[t.id].keep = True
+        self.outputs[name] = t
+
+    # -- statistics (used by bench.py / DESIGN.md for algorithmic work) ---------------------
+    def flops_per_image(self) -> int:
+        total = 0
+        for op in self.ops:
+            a = op.attrs
+            if op.kind == "gemm":
+                total += 2 * a["M"] * a["N"] * a["K_true"]
+            elif op.kind == "attention":
+                total += a["flops"]
+            elif op.kind == "dwconv":
+                total += 2 * a["OH"] * a["OW"] * a["C"] * a["k"] * a["k"]
+        return total
+
+    def weight_bytes(self) -> int:
+        return sum(c.host.nbytes for c in self.consts)
+
+    # -- buffer planning ---------------------------------------------------------------------
+    def plan_buffers(self) -> Tuple[Dict[int, int], List[int]]:
+        """Greedy liveness-based slab assignment.  Returns (tensor id -> slab, slab bytes
+        per image).  A tensor's slab is recycled after its last reader; outputs of an op are
+        placed before its inputs are released, so a kernel never reads and writes one slab."""
+        last_use: Dict[int, int] = {}
+        for i, op in enumerate(self.ops):
+            for t in op.inputs:
+                last_use[t] = i
+            for t in ([op.output] if op.output is not None else []) + op.extra_outputs:
+                last_use[t] = max(last_use.get(t, i), i)
+        slabs: List[int] = []
+        free: List[int] = []
+        assign: Dict[int, int] = {}
+        for i, op in enumerate(self.ops):
+            outs = ([op.output] if op.output is not None else []) + op.extra_outputs
+            for out in outs:
+                if out in assign:
+                    continue
+                need = self.tensors[out].bytes_per_image
+                best = None
+                for s_ in free:
+                    if slabs[s_] >= need and (best is None or slabs[s_] < slabs[best]):
+                        best = s_
+                if best is None and free:
+                    best = max(free, key=lambda s_: slabs[s_])  # grow the largest free slab
+                    slabs[best] = need
+                if best is None:
+                    slabs.append(need)
+                    best = len(slabs) - 1
+                else:
+                    free.remove(best)
+                assign[out] = best
+            for t in set(op.inputs + outs):
+                if last_use.get(t) == i and not self.tensors[t].keep and t in assign:
+                    if assign[t] not in free:
+                        free.append(assign[t])
+        return assign, slabs
+
+    # -- device side ------------------------------------------------------------------------
+    def upload(self, device="cuda"):
+        import torch
+        if self._dev_consts is not None and self._dev_consts_device == device:
+            return
+        self._dev_consts_device = device
+        dev = []
+        for c in self.consts:
+            h = c.host
+            if h.dtype == np.uint16:
+                t = torch.from_numpy(h.view(np.int16).copy()).to(device)
+            else:
+                t = torch.from_numpy(h.copy()).to(device)
+            dev.append(t)
+        self._dev_consts = dev
+
+    def make_plan(self, batch: int, device: str = "cuda") -> "Plan":
+        return Plan(self, batch, device)
+
+
+# ---------------------------------------------------------------------------------------
+# Builder: one method per fused kernel
+# ---------------------------------------------------------------------------------------
+class Builder:
+    def __init__(self, weights: Dict[str, np.ndarray]):
+        self.w = weights
+        self.p = Program()
+
+    # -- weights ---------------------------------------------------------------------------
+    def wget(self, name: str) -> np.ndarray:
+        if name not in self.w:
+            raise KeyError(f"missing weight '{name}'")
+        return np.asarray(self.w[name], dtype=np.float32)
+
+    def bn(self, prefix: str, eps: float):
+        """Folded inference BatchNorm -> (scale, shift).  Keras BN: layers/factory.py:22-37."""
+        return pack.bn_scale_shift(self.wget(prefix + "/gamma"), self.wget(prefix + "/beta"),
+                                   self.wget(prefix + "/moving_mean"),
+                                   self.wget(prefix + "/moving_variance"), eps)
+
+    # -- input -----------------------------------------------------------------------------
+    def image_input(self, H: int, W: int, cin: int) -> TRef:
+        """Caller's NHWC float image -> bf16 NHWC with padded channels (tfimm_hip_cast_input)."""
+        p = self.p
+        cpad = pack.pad_channels(cin)
+        raw = p.new_tensor(H * W, cin, H, W, dtype="raw", name="input")
+        raw.keep = True
+        p.input = raw
+        p.input_shape = (H, W, cin)
+        x = p.new_tensor(H * W, cpad, H, W, name="input_bf16")
+        p.add("cast_input", [raw], x, c_in=cin, c_out=cpad, cite="Keras input autocast")
+        return x
+
+    # -- convolution / dense -----------------------------------------------------------------
+    def conv(self, x: TRef, kernel: str, *, stride=1, padding=0, bn: Optional[str] = None,
+             bn_eps=1e-5, bias: Optional[str] = None, act="", residual: Optional[TRef] = None,
+             act_after_res=False, a_scale: Optional[TRef] = None, flatten=False,
+             remap=None, res_const=None, res_mod=0, cite="", name="") -> TRef:
+        """Conv2D (+ZeroPadding2D / "same") + folded BN / bias + activation + residual.
+
+        ``padding``: int (symmetric, as the reference's ZeroPadding2D + VALID), "same"
+        (TF asymmetric, layers/conv.py:61) or an explicit ``((top, bottom), (left, right))``.
+        """
+        p = self.p
+        k = self.wget(kernel)
+        kh, kw, cin, cout = k.shape
+        assert x.H > 0 and x.W > 0, "conv needs a spatial tensor"
+        if isinstance(padding, str):
+            if padding == "same":
+                OH, pt, _ = same_padding(x.H, kh, stride)
+                OW, pl, _ = same_padding(x.W, kw, stride)
+            elif padding == "valid":
+                pt = pl = 0
+                OH = (x.H - kh) // stride + 1
+                OW = (x.W - kw) // stride + 1
+            else:
+                raise ValueError(padding)
+        else:
+            if isinstance(padding, int):
+                pt = pb = pl = pr = padding
+            else:
+                (pt, pb), (pl, pr) = padding
+            OH = (x.H + pt + pb - kh) // stride + 1
+            OW = (x.W + pl + pr - kw) // stride + 1
+        scale = shift = None
+        if bn is not None:
+            scale, shift = self.bn(bn, bn_eps)
+        if bias is not None:
+            b = self.wget(bias)
+            shift = b if shift is None else shift + b * scale
+        M = OH * OW
+        out = p.new_tensor(M, cout, 0 if flatten else OH, 0 if flatten else OW, name=name or kernel)
+        consts = {}
+        attrs = dict(M=M, N=cout, K_true=kh * kw * cin, act=act, act_after_res=act_after_res,
+                     out_f32=0, res_mod=res_mod, remap=remap)
+        pointwise = (kh == 1 and kw == 1 and stride == 1 and pt == 0 and pl == 0 and x.C == cin)
+        if pointwise:
+            wt, bvec = pack.pack_dense(k.reshape(cin, cout) * (1.0 if scale is None else scale.reshape(1, cout)), shift)
+            attrs.update(mode=0, K=cin, lda=x.C, a_rows_per_image=x.rows)
+        else:
+            assert a_scale is None
+            wt, bvec, kk, mode = pack.pack_conv(k, scale, shift, x.C)
+            attrs.update(mode=mode, K=kk, H=x.H, W=x.W, Cin=x.C, KH=kh, KW=kw, stride=stride,
+                         pad_t=pt, pad_l=pl, OH=OH, OW=OW)
+        consts["wt"] = p.new_const(wt, kernel)
+        attrs["ldw"] = wt.shape[1]
+        if bvec is not None:
+            consts["bias"] = p.new_const(bvec, kernel + ":bias")
+        if res_const is not None:
+            consts["residual"] = res_const
+        ins = [x]
+        if residual is not None:
+            assert residual.C == cout and residual.rows == M
+            ins.append(residual)
+            attrs["has_residual"] = True
+            attrs["ldr"] = residual.C
+        if a_scale is not None:
+            assert a_scale.C == cin and pointwise
+            ins.append(a_scale)
+            attrs["has_scale"] = True
+        if remap is not None:
+            # rows land in a larger token buffer: (rows_in_per_image, rows_out_per_image, offset)
+            out.rows = remap[1]
+        p.add("gemm", ins, out, consts, cite=cite, **attrs)
+        return out
+
+    def dense(self, x: TRef, kernel: str, bias: Optional[str] = None, *, act="",
+              residual: Optional[TRef] = None, out_f32=False, row_select: Optional[Tuple[int, int]] = None,
+              in_cols: Optional[Tuple[int, int]] = None,
+              out: Optional[TRef] = None, out_col: int = 0, cite="", name="") -> TRef:
+        """tf.keras.layers.Dense (+ activation, + residual add).
+
+        ``row_select=(first_row, count)`` applies the layer to ``count`` rows per image
+        starting at ``first_row`` (e.g. the class token x[:, 0], vit.py:462) without a copy.
+        ``out``/``out_col``: write into columns [out_col, out_col+N) of an existing tensor
+        (tf.stack of the two DeiT heads, vit.py:474-476).
+        """
+        p = self.p
+        k = self.wget(kernel)
+        kin, kout = k.shape
+        if in_cols is None:
+            assert kin == x.C, f"{kernel}: in={kin} but tensor has C={x.C}"
+        else:
+            assert in_cols[1] == kin and in_cols[0] + kin <= x.C
+        wt, bvec = pack.pack_dense(k, None if bias is None else self.wget(bias))
+        rows = x.rows
+        attrs = dict(M=rows, N=kout, K=kin, K_true=kin, mode=0, lda=x.C, act=act, act_after_res=False,
+                     out_f32=1 if out_f32 else 0, res_mod=0, remap=None, ldw=wt.shape[1],
+                     a_rows_per_image=x.rows)
+        if row_select is not None:
+            first, count = row_select
+            assert count == 1, "row_select takes one row per image"
+            attrs.update(M=1, a_byte_offset=first * x.C * 2, lda=x.rows * x.C)
+            rows = 1
+        if in_cols is not None:
+            attrs["a_byte_offset"] = attrs.get("a_byte_offset", 0) + in_cols[0] * 2
+        if out is None:
+            out = p.new_tensor(rows, kout, dtype="f32" if out_f32 else "bf16", name=name or kernel)
+        else:
+            attrs["out_col"] = out_col
+        attrs["ldc"] = out.C
+        consts = {"wt": p.new_const(wt, kernel)}
+        if bvec is not None:
+            consts["bias"] = p.new_const(bvec, kernel + ":bias")
+        ins = [x]
+        if residual is not None:
+            assert residual.C == kout and residual.rows == rows
+            ins.append(residual)
+            attrs["has_residual"] = True
+            attrs["ldr"] = residual.C
+        p.add("gemm", ins, out, consts, cite=cite, **attrs)
+        return out
+
+    def empty(self, rows: int, C: int, dtype="bf16", name="") -> TRef:
+        return self.p.new_tensor(rows, C, dtype=dtype, name=name)
+
+    # -- normalisation -----------------------------------------------------------------------
+    def layernorm(self, x: TRef, prefix: str, eps: float, *, row_select=None, out: Optional[TRef] = None,
+                  out_col: int = 0, cite="", name="") -> TRef:
+        """LayerNormalization over the channel axis.  ``row_select=(row, 1)`` normalises one
+        token row per image; ``out``/``out_col`` write into a column slice of an existing
+        tensor (stacking the two DeiT token features without a copy)."""
+        p = self.p
+        g, b = self.wget(prefix + "/gamma"), self.wget(prefix + "/beta")
+        assert g.shape[0] == x.C
+        rows = x.rows if row_select is None else row_select[1]
+        if out is None:
+            out = p.new_tensor(rows, x.C, x.H if row_select is None else 0, x.W if row_select is None else 0,
+                               name=name or prefix)
+        else:
+            assert out.rows == rows and out_col + x.C <= out.C
+        consts = {"gamma": p.new_const(g, prefix + "/gamma"), "beta": p.new_const(b, prefix + "/beta")}
+        if row_select is None:
+            attrs = dict(rows=x.rows, x_stride=x.C, x_byte_offset=0)
+        else:
+            first, count = row_select
+            assert count == 1
+            attrs = dict(rows=1, x_stride=x.rows * x.C, x_byte_offset=first * x.C * 2)
+        p.add("layernorm", [x], out, consts, cite=cite, eps=float(eps), d=x.C, y_stride=out.C,
+              y_byte_offset=out_col * 2, **attrs)
+        return out
+
+    # -- attention ---------------------------------------------------------------------------
+    def attention(self, qkv: TRef, heads: int, scale: float, *, window=0, shift=0, res=(0, 0),
+                  rel_bias: Optional[np.ndarray] = None, cite="", name="") -> TRef:
+        p = self.p
+        d = qkv.C // 3
+        hd = d // heads
+        out = p.new_tensor(qkv.rows, d, qkv.H, qkv.W, name=name or "attn")
+        consts = {}
+        if rel_bias is not None:
+            consts["rel_bias"] = p.new_const(np.ascontiguousarray(rel_bias, dtype=np.float32), name + ":rel_bias")
+        n = window * window if window else qkv.rows
+        nseq = (qkv.rows // n)
+        p.add("attention", [qkv], out, consts, cite=cite, heads=heads, hd=hd, scale=float(scale),
+              window=window, shift=shift, res_h=res[0], res_w=res[1], n_tokens=qkv.rows,
+              flops=4 * nseq * heads * n * n * hd)
+        return out
+
+    # -- pooling / misc ------------------------------------------------------------------------
+    def maxpool(self, x: TRef, k: int, stride: int, pad: int, cite="") -> TRef:
+        OH = (x.H + 2 * pad - k) // stride + 1
+        OW = (x.W + 2 * pad - k) // stride + 1
+        out = self.p.new_tensor(OH * OW, x.C, OH, OW, name="maxpool")
+        self.p.add("maxpool", [x], out, cite=cite, H=x.H, W=x.W, C=x.C, k=k, stride=stride, pad=pad, OH=OH, OW=OW)
+        return out
+
+    def mean_rows(self, x: TRef, out_f32=False, cite="", name="") -> TRef:
+        out = self.p.new_tensor(1, x.C, dtype="f32" if out_f32 else "bf16", name=name or "mean")
+        self.p.add("mean_rows", [x], out, cite=cite, R=x.rows, C=x.C, out_f32=1 if out_f32 else 0)
+        return out
+
+    def token_rows(self, dst: TRef, rows_host: np.ndarray, cite="") -> None:
+        """Write constant rows (class / distillation token + their pos_embed) into the first
+        rows of every image of ``dst`` (tfimm_hip_bcast_rows)."""
+        bits = pack.to_bf16_bits(rows_host)
+        cid = self.p.new_const(bits, "token_rows")
+        self.p.add("bcast_rows", [dst], dst, {"src": cid}, cite=cite, n_rows=rows_host.shape[0],
+                   d=rows_host.shape[1], dst_rows=dst.rows)
+
+    def dwconv(self, x: TRef, kernel: str, *, stride=1, padding=0, bn=None, bn_eps=1e-5, bias=None,
+               act="", squeeze=False, cite="", name=""):
+        """DepthwiseConv2D + folded BN / bias + activation; optionally also emits the
+        per-(image, channel) sums of its output for a following SqueezeExcite."""
+        p = self.p
+        k = self.wget(kernel)
+        kh, kw, c, _ = k.shape
+        assert kh == kw and c == x.C
+        if padding == "same":
+            OH, pt, _ = same_padding(x.H, kh, stride)
+            OW, pl, _ = same_padding(x.W, kw, stride)
+        else:
+            pt = pl = int(padding)
+            OH = (x.H + 2 * pt - kh) // stride + 1
+            OW = (x.W + 2 * pl - kw) // stride + 1
+        scale = shift = None
+        if bn is not None:
+            scale, shift = self.bn(bn, bn_eps)
+        if bias is not None:
+            b = self.wget(bias)
+            shift = b if shift is None else shift + b * scale
+        w, bvec = pack.pack_depthwise(k, scale, shift)
+        out = p.new_tensor(OH * OW, c, OH, OW, name=name or kernel)
+        consts = {"w": p.new_const(w, kernel)}
+        if bvec is not None:
+            consts["bias"] = p.new_const(bvec, kernel + ":bias")
+        sums = None
+        ins = [x]
+        if squeeze:
+            sums = p.new_tensor(1, c, dtype="f32", name=(name or kernel) + ":sums")
+        p.add("dwconv", ins, out, consts, cite=cite, extra_outputs=[sums] if sums is not None else [],
+              H=x.H, W=x.W, C=c, k=kh, stride=stride, pad_t=pt, pad_l=pl, OH=OH, OW=OW, act=act,
+              sums=None if sums is None else sums.id)
+        return out, sums
+
+    def se_gate(self, sums: TRef, count: int, w_reduce: str, b_reduce: str, w_expand: str, b_expand: str,
+                act: str, gate_act="sigmoid", cite="") -> TRef:
+        p = self.p
+        w1 = self.wget(w_reduce)  # (1,1,C,rd)
+        w2 = self.wget(w_expand)  # (1,1,rd,C)
+        c, rd = w1.shape[2], w1.shape[3]
+        consts = {
+            "w1": p.new_const(np.ascontiguousarray(w1[0, 0].T), w_reduce),
+            "b1": p.new_const(self.wget(b_reduce), b_reduce),
+            "w2": p.new_const(np.ascontiguousarray(w2[0, 0].T), w_expand),
+            "b2": p.new_const(self.wget(b_expand), b_expand),
+        }
+        gate = p.new_tensor(1, c, dtype="f32", name="se_gate")
+        p.add("se_gate", [sums], gate, consts, cite=cite, C=c, rd=rd, inv_count=1.0 / count, act=act,
+              gate_act=gate_act)
+        return gate
+
+    def scale_channels(self, x: TRef, gate: TRef, residual: Optional[TRef] = None, relu_after=False, cite="") -> TRef:
+        out = self.p.new_tensor(x.rows, x.C, x.H, x.W, name="se_scaled")
+        ins = [x, gate] + ([residual] if residual is not None else [])
+        self.p.add("scale_channels", ins, out, cite=cite, R=x.rows, C=x.C, has_residual=residual is not None,
+                   act_after=1 if relu_after else 0)
+        return out
+
+    def patch_merge_ln(self, x: TRef, prefix: str, eps: float, cite="") -> TRef:
+        p = self.p
+        g, b = self.wget(prefix + "/gamma"), self.wget(prefix + "/beta")
+        assert g.shape[0] == 4 * x.C
+        out = p.new_tensor((x.H // 2) * (x.W // 2), 4 * x.C, x.H // 2, x.W // 2, name="patch_merge")
+        consts = {"gamma": p.new_const(g, prefix + "/gamma"), "beta": p.new_const(b, prefix + "/beta")}
+        p.add("patch_merge_ln", [x], out, consts, cite=cite, H=x.H, W=x.W, C=x.C, eps=float(eps))
+        return out
+
+    def reshape(self, x: TRef, rows: int, C: int, H=0, W=0) -> TRef:
+        """Free reinterpretation of a contiguous tensor (tf.reshape)."""
+        assert rows * C == x.rows * x.C
+        out = TRef(x.id, rows, C, H, W, x.dtype, x.keep, x.name)
+        return out
+
+
+# ---------------------------------------------------------------------------------------
+# Plan: a program bound to device buffers for one batch size
+# ---------------------------------------------------------------------------------------
+class Plan:
+    def __init__(self, prog: Program, batch: int, device: str = "cuda"):
+        """``device="cpu"`` builds the same call list over host buffers; it can only be used
+        to inspect / marshal-check the plan (tests without a GPU) -- launching it fails."""
+        import torch
+        from . import ffi
+        self.ffi = ffi
+        self.prog = prog
+        self.batch = batch
+        self.device = device
+        prog.upload(device)
+        assign, slabs = prog.plan_buffers()
+        self.slab_bytes = [s * batch for s in slabs]
+        self.slabs = [torch.empty(max(n, 16), dtype=torch.uint8, device=device) for n in self.slab_bytes]
+        self.assign = assign
+        self._keepalive = []
+        self.calls: List[Tuple[Callable, tuple]] = []
+        self._input_patch = None
+        self._build()
+
+    # pointers ----------------------------------------------------------------------------------
+    def tptr(self, tid: int) -> int:
+        return self.slabs[self.assign[tid]].data_ptr()
+
+    def cptr(self, cid: Optional[int]) -> Optional[int]:
+        if cid is None:
+            return None
+        return self.prog._dev_consts[cid].data_ptr()
+
+    def tensor_view(self, t: TRef):
+        """torch view of an activation tensor (for outputs / features)."""
+        import torch
+        slab = self.slabs[self.assign[t.id]]
+        n = self.batch * t.rows * t.C
+        if t.dtype == "f32":
+            return slab[: n * 4].view(torch.float32).view(self.batch, t.rows, t.C)
+        return slab[: n * 2].view(torch.bfloat16).view(self.batch, t.rows, t.C)
+
+    # build ---------------------------------------------------------------------------------------
+    def _build(self):
+        ffi, lib, B = self.ffi, self.ffi.lib, self.batch
+        prog = self.prog
+        for op in prog.ops:
+            a = op.attrs
+            k = op.kind
+            if k == "cast_input":
+                out = self.tptr(op.output)
+                H, W, cin = prog.input_shape
+                self._input_patch = (len(self.calls), out, B * H * W, a["c_in"], a["c_out"])
+                self.calls.append((lib.tfimm_hip_cast_input, None))  # args patched per call
+            elif k == "gemm":
+                d = ffi.GemmDesc()
+                a_ptr = self.tptr(op.inputs[0])
+                d.mode = a["mode"]
+                d.M = a["M"] * B
+                d.N, d.K = a["N"], a["K"]
+                d.ldw = a["ldw"]
+                if a["mode"] == 0:
+                    d.lda = a["lda"]
+                    a_ptr += a.get("a_byte_offset", 0)
+                    d.rows_per_image = a.get("a_rows_per_image", 0)
+                else:
+                    d.B, d.H, d.W, d.Cin = B, a["H"], a["W"], a["Cin"]
+                    d.KH, d.KW, d.stride = a["KH"], a["KW"], a["stride"]
+                    d.pad_t, d.pad_l, d.OH, d.OW = a["pad_t"], a["pad_l"], a["OH"], a["OW"]
+                d.a = a_ptr
+                d.wt = self.cptr(op.consts["wt"])
+                d.bias = self.cptr(op.consts.get("bias"))
+                out_t = prog.tensors[op.output]
+                out_ptr = self.tptr(out_t.id) + a.get("out_col", 0) * out_t.itemsize
+                d.out = out_ptr
+                d.ldc = a.get("ldc", out_t.C)
+                d.out_f32 = a["out_f32"]
+                d.act = ffi.ACT[a["act"]]
+                d.act_after_res = 1 if a["act_after_res"] else 0
+                idx = 1
+                if a.get("has_residual"):
+                    d.residual = self.tptr(op.inputs[idx])
+                    idx += 1
+                    d.ldr = a["ldr"]
+                elif "residual" in op.consts:
+                    d.residual = self.cptr(op.consts["residual"])
+                    d.ldr = a["N"]
+                d.res_mod = a.get("res_mod", 0)
+                if a.get("has_scale"):
+                    d.a_scale = self.tptr(op.inputs[idx])
+                    d.rows_per_image = a["a_rows_per_image"]
+                if a.get("remap"):
+                    d.remap_in, d.remap_out, d.remap_off = a["remap"]
+                self._keepalive.append(d)
+                self.calls.append((lib.tfimm_hip_gemm, (C.byref(d),)))
+            elif k == "layernorm":
+                xp = self.tptr(op.inputs[0]) + a["x_byte_offset"]
+                self.calls.append((lib.tfimm_hip_layernorm,
+                                   (xp, self.tptr(op.output) + a["y_byte_offset"], self.cptr(op.consts["gamma"]),
+                                    self.cptr(op.consts["beta"]), B * a["rows"], a["d"], a["x_stride"],
+                                    a["y_stride"], a["eps"])))
+            elif k == "attention":
+                d = ffi.AttnDesc()
+                d.qkv = self.tptr(op.inputs[0])
+                d.out = self.tptr(op.output)
+                d.rel_bias = self.cptr(op.consts.get("rel_bias"))
+                d.batch, d.n_tokens, d.heads, d.hd = B, a["n_tokens"], a["heads"], a["hd"]
+                d.scale = a["scale"]
+                d.window, d.shift, d.res_h, d.res_w = a["window"], a["shift"], a["res_h"], a["res_w"]
+                self._keepalive.append(d)
+                self.calls.append((lib.tfimm_hip_attention, (C.byref(d),)))
+            elif k == "maxpool":
+                self.calls.append((lib.tfimm_hip_maxpool,
+                                   (self.tptr(op.inputs[0]), self.tptr(op.output), B, a["H"], a["W"], a["C"],
+                                    a["k"], a["stride"], a["pad"], a["OH"], a["OW"])))
+            elif k == "mean_rows":
+                self.calls.append((lib.tfimm_hip_mean_rows,
+                                   (self.tptr(op.inputs[0]), self.tptr(op.output), B, a["R"], a["C"], a["out_f32"])))
+            elif k == "bcast_rows":
+                self.calls.append((lib.tfimm_hip_bcast_rows,
+                                   (self.cptr(op.consts["src"]), self.tptr(op.output), B, a["n_rows"], a["d"],
+                                    a["dst_rows"])))
+            elif k == "dwconv":
+                sums_ptr = None
+                if a["sums"] is not None:
+                    sums_ptr = self.tptr(a["sums"])
+                    self.calls.append(("memset", (sums_ptr, B * a["C"] * 4)))
+                self.calls.append((lib.tfimm_hip_dwconv,
+                                   (self.tptr(op.inputs[0]), self.cptr(op.consts["w"]), self.cptr(op.consts.get("bias")),
+                                    self.tptr(op.output), sums_ptr, B, a["H"], a["W"], a["C"], a["k"], a["stride"],
+                                    a["pad_t"], a["pad_l"], a["OH"], a["OW"], ffi.ACT[a["act"]])))
+            elif k == "se_gate":
+                self.calls.append((lib.tfimm_hip_se_gate,
+                                   (self.tptr(op.inputs[0]), a["inv_count"], self.cptr(op.consts["w1"]),
+                                    self.cptr(op.consts["b1"]), self.cptr(op.consts["w2"]), self.cptr(op.consts["b2"]),
+                                    self.tptr(op.output), B, a["C"], a["rd"], ffi.ACT[a["act"]], ffi.ACT[a["gate_act"]])))
+            elif k == "scale_channels":
+                res = self.tptr(op.inputs[2]) if a["has_residual"] else None
+                self.calls.append((lib.tfimm_hip_scale_channels,
+                                   (self.tptr(op.inputs[0]), self.tptr(op.inputs[1]), res, self.tptr(op.output), B,
+                                    a["R"], a["C"], a["act_after"])))
+            elif k == "patch_merge_ln":
+                self.calls.append((lib.tfimm_hip_patch_merge_ln,
+                                   (self.tptr(op.inputs[0]), self.tptr(op.output), self.cptr(op.consts["gamma"]),
+                                    self.cptr(op.consts["beta"]), B, a["H"], a["W"], a["C"], a["eps"])))
+            else:
+                raise NotImplementedError(k)
+
+    def check_marshalling(self):
+        """Convert every recorded argument through the ctypes prototypes (no launch): catches
+        arity / type slips in the call list without a GPU.  Returns the number of calls."""
+        n = 0
+        for i, (fn, args) in enumerate(self.calls):
+            if fn == "memset":
+                assert len(args) == 2
+                continue
+            if args is None:  # cast_input: patched per call
+                _, out, npix, c_in, c_out = self._input_patch
+                args = (0, 0, out, npix, c_in, c_out)
+            protos = fn.argtypes
+            if len(args) + 1 != len(protos):
+                raise TypeError(f"call {i} ({fn.__name__}): {len(args) + 1} args for {len(protos)} parameters")
+            for a, pt in zip(args, protos):
+                pt.from_param(a)
+            n += 1
+        return n
+
+    # run -------------------------------------------------------------------------------------------
+    def run(self, x_dev, stream_ptr: Optional[int] = None):
+        """Enqueue the whole program on the current torch stream.  ``x_dev``: contiguous cuda
+        tensor (B, H, W, C) float32 or bfloat16."""
+        import torch
+        ffi = self.ffi
+        if stream_ptr is None:
+            stream_ptr = torch.cuda.current_stream().cuda_stream
+        st = C.c_void_p(stream_ptr)
+        idx, out, npix, c_in, c_out = self._input_patch
+        in_dtype = 1 if x_dev.dtype == torch.bfloat16 else 0
+        for i, (fn, args) in enumerate(self.calls):
+            if i == idx:
+                rc = fn(x_dev.data_ptr(), in_dtype, out, npix, c_in, c_out, st)
+            elif fn == "memset":
+                ffi.check(_hip_memset_async(args[0], args[1], stream_ptr), "hipMemsetAsync")
+                continue
+            else:
+                rc = fn(*args, st)
+            if rc != 0:
+                ffi.check(rc, f"op {i} ({getattr(fn, '__name__', fn)})")
+
+
+_hip = None
+
+
+def _hip_memset_async(ptr: int, nbytes: int, stream_ptr: int) -> int:
+    """hipMemsetAsync via the HIP runtime that libtfimm_hip.so is linked against."""
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemsetAsync.restype = C.c_int
+        _hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    return _hip.hipMemsetAsync(C.c_void_p(ptr), 0, nbytes, C.c_void_p(stream_ptr))

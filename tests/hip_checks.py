@@ -1,0 +1,471 @@
+"""Op-level parity cases: every HIP kernel vs. the CPU oracle ops on identical bf16-valued inputs.
+
+Each case returns ``(err, tol)`` with err = max|hip - ref| / (max|ref| + 1e-6).  Inputs are
+rounded to bf16 first and the reference is evaluated in fp32 on those values, so the only
+differences are accumulation order and the final bf16 rounding of the output
+(bf16 has 8 significant bits: 2^-8 = 3.9e-3; tolerance 1e-2 rel-to-max for bf16 outputs,
+1e-3 for fp32 outputs).  Used by tests/test_gpu_ops.py (pytest -m gpu) and by
+tools/gpu_selftest.py (prints the full table without stopping at the first failure).
+"""
+import math
+
+import numpy as np
+import torch
+
+from oracle import ops as O
+from tfimm.engine import pack
+
+TOL_BF16 = 1e-2
+TOL_F32 = 1e-3
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+def _bf(a):
+    """round fp32 numpy -> bf16-representable fp32 numpy"""
+    return pack.bf16_bits_to_f32(pack.to_bf16_bits(np.asarray(a, dtype=np.float32))).reshape(np.shape(a))
+
+
+def _err(got, ref):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    if not np.all(np.isfinite(got)):
+        return float("inf")
+    return float(np.max(np.abs(got - ref)) / (np.max(np.abs(ref)) + 1e-6))
+
+
+def _cpu(t):
+    return t.float().cpu().numpy()
+
+
+CASES = {}
+
+
+def case(name):
+    def deco(fn):
+        CASES[name] = fn
+        return fn
+    return deco
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM (dense)
+# ---------------------------------------------------------------------------------------------
+def _gemm_case(M, K, N, *, act="", bias=True, residual=False, act_after_res=False, out_f32=False, tile=0,
+               seed=0, res_mod=0, remap=None):
+    import hip_ops as H
+    r = _rng(seed)
+    a = _bf(r.standard_normal((M, K)))
+    w = _bf(r.standard_normal((K, N)) / math.sqrt(K))
+    b = r.standard_normal(N).astype(np.float32) if bias else None
+    nres = res_mod if res_mod else M
+    res = _bf(r.standard_normal((nres, N))) if residual else None
+    wt, _ = pack.pack_dense(w, None)
+    ref = a.astype(np.float64) @ w.astype(np.float64)
+    if bias:
+        ref = ref + b
+    ref_t = torch.from_numpy(ref.astype(np.float32))
+    if not act_after_res:
+        ref_t = O.activation(ref_t, act)
+    if residual:
+        idx = np.arange(M) % nres
+        ref_t = ref_t + torch.from_numpy(res[idx])
+    if act_after_res:
+        ref_t = O.activation(ref_t, act)
+    ref = ref_t.numpy()
+    out_rows = None
+    if remap:
+        rin, rout, roff = remap
+        out_rows = (M // rin) * rout
+    got = H.gemm(H.dev_bf16(a), H.dev_bits(wt), N, K, bias=None if b is None else H.dev_f32(b),
+                 residual=None if res is None else H.dev_bf16(res), act=act, act_after_res=act_after_res,
+                 out_f32=out_f32, tile_hint=tile, res_mod=res_mod, remap=remap, out_rows=out_rows)
+    H.sync()
+    got = _cpu(got)
+    if remap:
+        rin, rout, roff = remap
+        rows = (np.arange(M) // rin) * rout + np.arange(M) % rin + roff
+        untouched = np.setdiff1d(np.arange(out_rows), rows)
+        assert np.all(got[untouched] == 0), "remap wrote outside its rows"
+        got = got[rows]
+    return _err(got, ref), (TOL_F32 if out_f32 else TOL_BF16)
+
+
+for _t in range(0, 7):
+    CASES[f"gemm_tile{_t}_256x192x320"] = (lambda t=_t: _gemm_case(256, 192, 320, tile=t, seed=1))
+    CASES[f"gemm_tile{_t}_ragged_333x200x150_gelu_res"] = (
+        lambda t=_t: _gemm_case(333, 200, 150, act="gelu", residual=True, tile=t, seed=2))
+CASES["gemm_vit_qkv_394x768x2304"] = lambda: _gemm_case(394, 768, 2304, seed=3)
+CASES["gemm_vit_fc2_394x3072x768_res"] = lambda: _gemm_case(394, 3072, 768, residual=True, seed=4)
+CASES["gemm_head_f32_8x768x1000"] = lambda: _gemm_case(8, 768, 1000, out_f32=True, seed=5)
+CASES["gemm_relu_after_res_512x64x256"] = lambda: _gemm_case(512, 64, 256, act="relu", residual=True,
+                                                             act_after_res=True, seed=6)
+CASES["gemm_swish_1000x24x144"] = lambda: _gemm_case(1000, 24, 144, act="swish", seed=7)
+CASES["gemm_scalar_K4_17x4x12"] = lambda: _gemm_case(34, 4, 12, seed=8)
+CASES["gemm_scalar_odd_70x5x7_f32"] = lambda: _gemm_case(70, 5, 7, out_f32=True, seed=9)
+CASES["gemm_nobias_130x72x40"] = lambda: _gemm_case(130, 72, 40, bias=False, seed=10)
+CASES["gemm_resmod_remap_392x64x96"] = lambda: _gemm_case(392, 64, 96, residual=True, res_mod=196,
+                                                          remap=(196, 197, 1), seed=11)
+CASES["gemm_tanh_64x128x64"] = lambda: _gemm_case(64, 128, 64, act="tanh", seed=12)
+CASES["gemm_sigmoid_relu6"] = lambda: max(_gemm_case(64, 64, 64, act="sigmoid", seed=13),
+                                          _gemm_case(64, 64, 64, act="relu6", seed=14))
+
+
+@case("gemm_se_scale_prologue")
+def _():
+    import hip_ops as H
+    r = _rng(20)
+    B, R, K, N = 3, 50, 48, 24
+    a = _bf(r.standard_normal((B * R, K)))
+    w = _bf(r.standard_normal((K, N)) / math.sqrt(K))
+    g = r.uniform(0.1, 1.0, (B, K)).astype(np.float32)
+    wt, _ = pack.pack_dense(w, None)
+    scaled = _bf(a.reshape(B, R, K) * g[:, None, :]).reshape(B * R, K)   # kernel re-rounds A*gate to bf16
+    ref = scaled.astype(np.float64) @ w.astype(np.float64)
+    got = H.gemm(H.dev_bf16(a), H.dev_bits(wt), N, K, a_scale=H.dev_f32(g), rows_per_image=R)
+    H.sync()
+    return _err(_cpu(got), ref), TOL_BF16
+
+
+@case("gemm_row_select_lda")
+def _():
+    """class-token select: A row b = x[b, 0, :] via lda = N_tokens * D (vit.py:462)."""
+    import hip_ops as H
+    r = _rng(21)
+    B, T, D, N = 5, 7, 64, 40
+    x = _bf(r.standard_normal((B, T, D)))
+    w = _bf(r.standard_normal((D, N)) / 8)
+    wt, _ = pack.pack_dense(w, None)
+    ref = x[:, 0, :].astype(np.float64) @ w.astype(np.float64)
+    got = H.gemm(H.dev_bf16(x), H.dev_bits(wt), N, D, M=B, lda=T * D, out_f32=True)
+    H.sync()
+    return _err(_cpu(got), ref), TOL_F32
+
+
+# ---------------------------------------------------------------------------------------------
+# convolutions through the GEMM gather modes
+# ---------------------------------------------------------------------------------------------
+def _conv_case(B, H, W, Cin, Cout, k, stride, padding, *, act="", bn=True, residual=False, seed=0, tile=0):
+    import hip_ops as Hh
+    r = _rng(seed)
+    x = _bf(r.standard_normal((B, H, W, Cin)))
+    kern = (r.standard_normal((k, k, Cin, Cout)) / math.sqrt(k * k * Cin)).astype(np.float32)
+    scale = r.uniform(0.5, 1.5, Cout).astype(np.float32) if bn else None
+    shift = r.standard_normal(Cout).astype(np.float32) if bn else None
+    cin_stored = pack.pad_channels(Cin) if Cin <= 4 else Cin
+    wt, bias, K, mode = pack.pack_conv(kern, scale, shift, cin_stored)
+    # reference uses the same folded+rounded weights
+    kf = kern * (scale.reshape(1, 1, 1, -1) if bn else 1.0)
+    kf = _bf(kf)
+    xt = torch.from_numpy(x)
+    if padding == "same":
+        y = O.conv2d(xt, torch.from_numpy(kf), None, stride=stride, padding="same")
+        pt, _ = O.same_pad_amounts(H, k, stride)
+        pl, _ = O.same_pad_amounts(W, k, stride)
+    else:
+        y = O.conv2d(O.zero_pad2d(xt, padding), torch.from_numpy(kf), None, stride=stride)
+        pt = pl = padding
+    if bn:
+        y = y + torch.from_numpy(shift)
+    OH, OW = y.shape[1], y.shape[2]
+    res = _bf(r.standard_normal((B, OH, OW, Cout))) if residual else None
+    if residual:
+        y = O.activation(y + torch.from_numpy(res), act)
+    else:
+        y = O.activation(y, act)
+    xd = Hh.dev_bf16(x)
+    if cin_stored != Cin:
+        xd = Hh.cast_input(xd, cin_stored)
+    conv = dict(mode=mode, B=B, H=H, W=W, Cin=cin_stored, KH=k, KW=k, stride=stride, pad_t=pt, pad_l=pl, OH=OH, OW=OW)
+    got = Hh.gemm(xd, Hh.dev_bits(wt), Cout, K, bias=None if bias is None else Hh.dev_f32(bias),
+                  residual=None if res is None else Hh.dev_bf16(res.reshape(-1, Cout)), act=act,
+                  act_after_res=residual, conv=conv, tile_hint=tile)
+    Hh.sync()
+    return _err(_cpu(got).reshape(B, OH, OW, Cout), y.numpy()), TOL_BF16
+
+
+CASES["conv3x3_s1_p1_64to64_relu"] = lambda: _conv_case(2, 14, 14, 64, 64, 3, 1, 1, act="relu", seed=30)
+CASES["conv3x3_s2_p1_128to128_relu"] = lambda: _conv_case(2, 28, 28, 128, 128, 3, 2, 1, act="relu", seed=31)
+CASES["conv3x3_s1_p1_res_relu_after"] = lambda: _conv_case(1, 9, 11, 32, 48, 3, 1, 1, act="relu", residual=True, seed=32)
+CASES["conv1x1_s2_256to512"] = lambda: _conv_case(2, 14, 14, 256, 512, 1, 2, 0, seed=33)
+CASES["conv7x7_s2_p3_rgb_stem"] = lambda: _conv_case(2, 64, 64, 3, 64, 7, 2, 3, act="relu", seed=34)
+CASES["conv16x16_s16_rgb_patch"] = lambda: _conv_case(2, 64, 64, 3, 96, 16, 16, 0, bn=False, seed=35)
+CASES["conv4x4_s4_rgb_patch"] = lambda: _conv_case(2, 32, 32, 3, 128, 4, 4, 0, seed=36)
+CASES["conv3x3_s2_same_rgb_odd"] = lambda: _conv_case(2, 33, 33, 3, 48, 3, 2, "same", act="swish", seed=37)
+CASES["conv3x3_s2_same_even"] = lambda: _conv_case(2, 20, 20, 16, 24, 3, 2, "same", seed=38)
+CASES["conv3x3_scalar_cin6"] = lambda: _conv_case(2, 8, 8, 6, 10, 3, 1, 1, act="relu", seed=39)
+CASES["conv3x3_scalar_cin2_s2"] = lambda: _conv_case(3, 9, 9, 2, 4, 3, 2, 1, seed=40)
+CASES["conv1ch_8x8_patch"] = lambda: _conv_case(2, 32, 32, 1, 4, 8, 8, 0, bn=False, seed=41)
+for _t in (1, 2, 3, 4, 5, 6):
+    CASES[f"conv3x3_tile{_t}"] = (lambda t=_t: _conv_case(2, 16, 16, 64, 96, 3, 1, 1, act="relu", seed=42, tile=t))
+
+
+# ---------------------------------------------------------------------------------------------
+# row ops
+# ---------------------------------------------------------------------------------------------
+def _ln_case(rows, d, eps, seed):
+    import hip_ops as H
+    r = _rng(seed)
+    x = _bf(r.standard_normal((rows, d)) * 2 + 0.5)
+    g = r.uniform(0.5, 1.5, d).astype(np.float32)
+    b = r.standard_normal(d).astype(np.float32)
+    ref = O.layer_norm(torch.from_numpy(x), torch.from_numpy(g), torch.from_numpy(b), eps).numpy()
+    got = H.layernorm(H.dev_bf16(x), H.dev_f32(g), H.dev_f32(b), eps)
+    H.sync()
+    return _err(_cpu(got), ref), TOL_BF16
+
+
+CASES["layernorm_768"] = lambda: _ln_case(197 * 3, 768, 1e-6, 50)
+CASES["layernorm_192"] = lambda: _ln_case(50, 192, 1e-6, 51)
+CASES["layernorm_1024"] = lambda: _ln_case(33, 1024, 1e-5, 52)
+CASES["layernorm_2048"] = lambda: _ln_case(9, 2048, 1e-5, 53)
+CASES["layernorm_4096"] = lambda: _ln_case(5, 4096, 1e-5, 54)
+CASES["layernorm_generic_d4"] = lambda: _ln_case(34, 4, 1e-6, 55)
+CASES["layernorm_generic_d100"] = lambda: _ln_case(7, 100, 1e-5, 56)
+
+
+@case("layernorm_strided_rows")
+def _():
+    import hip_ops as H
+    r = _rng(57)
+    B, T, D = 6, 5, 64
+    x = _bf(r.standard_normal((B, T, D)))
+    g = r.uniform(0.5, 1.5, D).astype(np.float32)
+    b = r.standard_normal(D).astype(np.float32)
+    ref = O.layer_norm(torch.from_numpy(x[:, 0]), torch.from_numpy(g), torch.from_numpy(b), 1e-6).numpy()
+    got = H.layernorm(H.dev_bf16(x), H.dev_f32(g), H.dev_f32(b), 1e-6, rows=B, d=D, xs=T * D, ys=D)
+    H.sync()
+    return _err(_cpu(got), ref), TOL_BF16
+
+
+def _attn_ref(qkv, B, N, heads, hd, scale):
+    q = qkv.reshape(B, N, 3, heads, hd).transpose(2, 0, 3, 1, 4).astype(np.float64)
+    s = scale * (q[0] @ q[1].transpose(0, 1, 3, 2))
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(-1, keepdims=True)
+    o = p @ q[2]
+    return o.transpose(0, 2, 1, 3).reshape(B * N, heads * hd)
+
+
+def _attn_case(B, N, heads, hd, seed, spike=False):
+    import hip_ops as H
+    r = _rng(seed)
+    qkv = r.standard_normal((B * N, 3 * heads * hd))
+    if spike:  # force a late running-max jump in the online softmax (rescale branch)
+        qkv[N - 1, heads * hd: heads * hd + hd] = 6.0 * np.sign(qkv[0, :hd])
+    qkv = _bf(qkv)
+    scale = hd ** -0.5
+    ref = _attn_ref(qkv, B, N, heads, hd, scale)
+    got = H.attention(H.dev_bf16(qkv), B, N, heads, hd, scale)
+    H.sync()
+    return _err(_cpu(got), ref), 1.5e-2   # P is rounded to bf16 before P.V
+
+
+CASES["attn_vit_197_h3_hd64"] = lambda: _attn_case(2, 197, 3, 64, 60)
+CASES["attn_vit_197_spike"] = lambda: _attn_case(1, 197, 2, 64, 61, spike=True)
+CASES["attn_64_exact_block"] = lambda: _attn_case(2, 64, 2, 64, 62)
+CASES["attn_65_tail1"] = lambda: _attn_case(1, 65, 1, 64, 63)
+CASES["attn_577_hd64"] = lambda: _attn_case(1, 577, 2, 64, 64)
+CASES["attn_mini_17_hd2"] = lambda: _attn_case(3, 17, 2, 2, 65)
+CASES["attn_50_hd32"] = lambda: _attn_case(2, 50, 4, 32, 66)
+CASES["attn_hd48"] = lambda: _attn_case(2, 33, 2, 48, 67)
+
+
+def _swin_ref(x_qkv, B, Hr, Wr, heads, hd, ws, shift, table):
+    """Literal restatement of swin.py:287-318 + WindowAttention.call on a packed qkv tensor."""
+    C = heads * hd
+    n = ws * ws
+    t = torch.from_numpy(x_qkv).reshape(B, Hr, Wr, 3 * C)
+    t = torch.roll(t, shifts=(-shift, -shift), dims=(1, 2))
+    t = t.reshape(B, Hr // ws, ws, Wr // ws, ws, 3 * C).permute(0, 1, 3, 2, 4, 5).reshape(-1, n, 3 * C)
+    qkv = t.reshape(-1, n, 3, heads, hd).permute(2, 0, 3, 1, 4).double()
+    q, k, v = qkv[0] * (hd ** -0.5), qkv[1], qkv[2]
+    attn = q @ k.transpose(-1, -2)
+    coords = np.stack(np.meshgrid(np.arange(ws), np.arange(ws), indexing="ij")).reshape(2, -1)
+    rel = (coords[:, :, None] - coords[:, None, :]).transpose(1, 2, 0).copy()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    index = rel.sum(-1)
+    bias = torch.from_numpy(table[index.reshape(-1)].reshape(n, n, heads)).permute(2, 0, 1).double()
+    attn = attn + bias.unsqueeze(0)
+    if shift > 0:
+        img = np.zeros((1, Hr, Wr, 1))
+        cnt = 0
+        for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+                img[:, hs, wsl, :] = cnt
+                cnt += 1
+        mw = img.reshape(1, Hr // ws, ws, Wr // ws, ws, 1).transpose(0, 1, 3, 2, 4, 5).reshape(-1, n)
+        mask = mw[:, None, :] - mw[:, :, None]
+        mask = np.where(mask != 0, -100.0, 0.0)
+        nw = mask.shape[0]
+        attn = attn.reshape(-1, nw, heads, n, n) + torch.from_numpy(mask)[None, :, None]
+        attn = attn.reshape(-1, heads, n, n)
+    attn = torch.softmax(attn, -1)
+    o = (attn @ v).permute(0, 2, 1, 3).reshape(-1, ws, ws, C)
+    o = o.reshape(B, Hr // ws, Wr // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hr, Wr, C)
+    o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    return o.reshape(B * Hr * Wr, C).numpy(), index
+
+
+def _swin_case(B, Hr, Wr, heads, hd, ws, shift, seed):
+    import hip_ops as H
+    r = _rng(seed)
+    C = heads * hd
+    qkv = _bf(r.standard_normal((B * Hr * Wr, 3 * C)))
+    table = r.standard_normal(((2 * ws - 1) ** 2, heads)).astype(np.float32)
+    ref, index = _swin_ref(qkv, B, Hr, Wr, heads, hd, ws, shift, table)
+    n = ws * ws
+    bias = table[index.reshape(-1)].reshape(n, n, heads).transpose(2, 0, 1).copy()
+    got = H.attention(H.dev_bf16(qkv), B, Hr * Wr, heads, hd, hd ** -0.5, window=ws, shift=shift, res=(Hr, Wr),
+                      rel_bias=H.dev_f32(bias))
+    H.sync()
+    return _err(_cpu(got), ref), 1.5e-2
+
+
+CASES["swin_w7_noshift_14x14_h4_hd32"] = lambda: _swin_case(2, 14, 14, 4, 32, 7, 0, 70)
+CASES["swin_w7_shift3_14x14_h4_hd32"] = lambda: _swin_case(2, 14, 14, 4, 32, 7, 3, 71)
+CASES["swin_w7_shift3_28x14_rect"] = lambda: _swin_case(1, 28, 14, 2, 32, 7, 3, 72)
+CASES["swin_w4_shift2_8x8_hd4"] = lambda: _swin_case(2, 8, 8, 1, 4, 4, 2, 73)
+CASES["swin_w12_shift6_24x24"] = lambda: _swin_case(1, 24, 24, 2, 32, 12, 6, 74)
+CASES["swin_w7_single_window"] = lambda: _swin_case(3, 7, 7, 2, 32, 7, 0, 75)
+
+
+@case("maxpool_3x3_s2_p1")
+def _():
+    import hip_ops as H
+    r = _rng(80)
+    x = _bf(np.maximum(r.standard_normal((2, 15, 15, 64)), 0))
+    ref = O.max_pool2d(O.zero_pad2d(torch.from_numpy(x), 1), 3, 2).numpy()
+    got = H.maxpool(H.dev_bf16(x), 3, 2, 1)
+    H.sync()
+    e1 = _err(_cpu(got), ref)
+    x = _bf(r.standard_normal((2, 9, 9, 6)))   # generic path; NEGATIVE values: zero padding wins at borders
+    ref = O.max_pool2d(O.zero_pad2d(torch.from_numpy(x), 1), 3, 2).numpy()
+    got = H.maxpool(H.dev_bf16(x), 3, 2, 1)
+    H.sync()
+    return max(e1, _err(_cpu(got), ref)), 1e-6
+
+
+@case("mean_rows")
+def _():
+    import hip_ops as H
+    r = _rng(81)
+    x = _bf(r.standard_normal((3, 49, 200)))
+    got = H.mean_rows(H.dev_bf16(x), out_f32=True)
+    got2 = H.mean_rows(H.dev_bf16(x), out_f32=False)
+    H.sync()
+    ref = x.mean(1)
+    return max(_err(_cpu(got), ref), _err(_cpu(got2), ref) / 10), 1e-3
+
+
+@case("bcast_rows")
+def _():
+    import hip_ops as H
+    r = _rng(82)
+    B, T, D, n = 4, 6, 40, 2
+    src = _bf(r.standard_normal((n, D)))
+    dst0 = _bf(r.standard_normal((B, T, D)))
+    dst = H.dev_bf16(dst0)
+    H.bcast_rows(H.dev_bf16(src), dst, B, n, D, T)
+    H.sync()
+    ref = dst0.copy()
+    ref[:, :n] = src
+    return _err(_cpu(dst), ref), 1e-6
+
+
+@case("cast_input_rgb_and_generic")
+def _():
+    import hip_ops as H
+    r = _rng(83)
+    x = r.standard_normal((2, 5, 7, 3)).astype(np.float32)
+    got = H.cast_input(torch.from_numpy(x).to(H.DEV), 4)
+    got5 = H.cast_input(torch.from_numpy(r.standard_normal((2, 3, 3, 5)).astype(np.float32)).to(H.DEV), 8)
+    gotb = H.cast_input(H.dev_bf16(x), 4)
+    H.sync()
+    ref = np.concatenate([_bf(x), np.zeros((2, 5, 7, 1), np.float32)], -1)
+    ok5 = float(np.abs(_cpu(got5)[..., 5:]).max())
+    return max(_err(_cpu(got), ref), _err(_cpu(gotb), ref), ok5), 1e-6
+
+
+def _dw_case(B, H, W, Cc, k, stride, padding, act, seed):
+    import hip_ops as Hh
+    r = _rng(seed)
+    x = _bf(r.standard_normal((B, H, W, Cc)))
+    kern = (r.standard_normal((k, k, Cc, 1)) / k).astype(np.float32)
+    scale = r.uniform(0.5, 1.5, Cc).astype(np.float32)
+    shift = r.standard_normal(Cc).astype(np.float32)
+    w, bias = pack.pack_depthwise(kern, scale, shift)
+    kf = torch.from_numpy(kern * scale.reshape(1, 1, -1, 1))
+    if padding == "same":
+        y = O.depthwise_conv2d(torch.from_numpy(x), kf, None, stride, "same")
+        pt, _ = O.same_pad_amounts(H, k, stride)
+        pl, _ = O.same_pad_amounts(W, k, stride)
+    else:
+        y = O.depthwise_conv2d(O.zero_pad2d(torch.from_numpy(x), padding), kf, None, stride)
+        pt = pl = padding
+    y = O.activation(y + torch.from_numpy(shift), act)
+    OH, OW = y.shape[1], y.shape[2]
+    got, sums = Hh.dwconv(Hh.dev_bf16(x), Hh.dev_f32(w), Hh.dev_f32(bias), k, stride, pt, pl, OH, OW, act=act,
+                          want_sums=True)
+    Hh.sync()
+    e = _err(_cpu(got), y.numpy())
+    es = _err(_cpu(sums), _cpu(got).sum((1, 2)))   # sums are of the stored bf16 outputs
+    return max(e, es / 10), TOL_BF16
+
+
+CASES["dwconv_k3_s1_same_c48"] = lambda: _dw_case(2, 19, 19, 48, 3, 1, "same", "swish", 90)
+CASES["dwconv_k3_s2_same_even"] = lambda: _dw_case(2, 20, 20, 144, 3, 2, "same", "swish", 91)
+CASES["dwconv_k5_s2_same_odd"] = lambda: _dw_case(2, 15, 15, 32, 5, 2, "same", "swish", 92)
+CASES["dwconv_k5_s2_same_even24"] = lambda: _dw_case(1, 24, 24, 16, 5, 2, "same", "swish", 93)
+CASES["dwconv_k7_p3_c96_linear"] = lambda: _dw_case(2, 14, 14, 96, 7, 1, 3, "", 94)
+CASES["dwconv_k3_p1_generic_c6"] = lambda: _dw_case(2, 8, 8, 6, 3, 1, 1, "relu", 95)
+
+
+@case("se_gate_and_scale")
+def _():
+    import hip_ops as H
+    r = _rng(96)
+    B, R, Cc, rd = 3, 25, 144, 6
+    x = _bf(r.standard_normal((B, R, Cc)))
+    w1 = (r.standard_normal((rd, Cc)) / 12).astype(np.float32)
+    b1 = r.standard_normal(rd).astype(np.float32)
+    w2 = (r.standard_normal((Cc, rd)) / 2).astype(np.float32)
+    b2 = r.standard_normal(Cc).astype(np.float32)
+    sums = x.sum(1)
+    mean = torch.from_numpy(sums / R)
+    hid = O.activation(mean @ torch.from_numpy(w1.T) + torch.from_numpy(b1), "swish")
+    gate = torch.sigmoid(hid @ torch.from_numpy(w2.T) + torch.from_numpy(b2)).numpy()
+    g = H.se_gate(H.dev_f32(sums), 1.0 / R, H.dev_f32(w1), H.dev_f32(b1), H.dev_f32(w2), H.dev_f32(b2), "swish")
+    res = _bf(r.standard_normal((B, R, Cc)))
+    y = H.scale_channels(H.dev_bf16(x), g, H.dev_bf16(res), relu_after=True)
+    H.sync()
+    ref_y = np.maximum(x * gate[:, None, :] + res, 0)
+    return max(_err(_cpu(g), gate), _err(_cpu(y), ref_y)), TOL_BF16
+
+
+@case("patch_merge_ln")
+def _():
+    import hip_ops as H
+    r = _rng(97)
+    B, Hh, Ww, Cc = 2, 6, 8, 16
+    x = _bf(r.standard_normal((B, Hh * Ww, Cc)))
+    g = r.uniform(0.5, 1.5, 4 * Cc).astype(np.float32)
+    b = r.standard_normal(4 * Cc).astype(np.float32)
+    t = torch.from_numpy(x).reshape(B, Hh, Ww, Cc)
+    cat = torch.cat((t[:, 0::2, 0::2], t[:, 1::2, 0::2], t[:, 0::2, 1::2], t[:, 1::2, 1::2]), -1)   # swin.py:353-357
+    ref = O.layer_norm(cat.reshape(B, -1, 4 * Cc), torch.from_numpy(g), torch.from_numpy(b), 1e-5).numpy()
+    got = H.patch_merge_ln(H.dev_bf16(x), H.dev_f32(g), H.dev_f32(b), Hh, Ww, 1e-5)
+    H.sync()
+    return _err(_cpu(got), ref), TOL_BF16
+
+
+def run_case(name):
+    out = CASES[name]()
+    err, tol = out
+    return float(err), float(tol)

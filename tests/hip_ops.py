@@ -1,0 +1,164 @@
+"""Thin torch-tensor wrappers over the C ABI for op-level parity tests (test helper).
+
+Every function takes/returns CUDA torch tensors (bf16 activations) and calls
+libtfimm_hip.so through tfimm.engine.ffi -- the same entry points the engine uses.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from tfimm.engine import ffi, pack
+
+lib = ffi.lib
+# On a box without a GPU the wrappers still marshal every argument and call into the library
+# (the launch then fails with a HIP error): lets the CPU suite dry-run the call plumbing.
+DEV = "cuda" if torch.cuda.is_available() else "cpu"
+
+
+def stream():
+    if DEV == "cpu":
+        return C.c_void_p(0)
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def sync():
+    if DEV == "cuda":
+        torch.cuda.synchronize()
+
+
+def dev_bf16(a) -> torch.Tensor:
+    t = torch.as_tensor(np.asarray(a), dtype=torch.float32)
+    return t.to(torch.bfloat16).to(DEV).contiguous()
+
+
+def dev_f32(a) -> torch.Tensor:
+    return torch.as_tensor(np.asarray(a), dtype=torch.float32).to(DEV).contiguous()
+
+
+def dev_bits(bits: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(bits.view(np.int16).copy()).to(DEV).view(torch.bfloat16)
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def gemm(a, wt, N, K, *, M=None, bias=None, residual=None, out=None, act="", act_after_res=False,
+         out_f32=False, lda=None, ldc=None, ldr=None, res_mod=0, remap=None, conv=None, a_scale=None,
+         rows_per_image=0, tile_hint=0, out_rows=None):
+    """conv: dict(mode, B, H, W, Cin, KH, KW, stride, pad_t, pad_l, OH, OW)."""
+    d = ffi.GemmDesc()
+    if conv is None:
+        M = M if M is not None else a.shape[0]
+        d.mode = 0
+        d.lda = lda if lda is not None else a.shape[-1]
+    else:
+        d.mode = conv["mode"]
+        d.B, d.H, d.W, d.Cin = conv["B"], conv["H"], conv["W"], conv["Cin"]
+        d.KH, d.KW, d.stride = conv["KH"], conv["KW"], conv["stride"]
+        d.pad_t, d.pad_l, d.OH, d.OW = conv["pad_t"], conv["pad_l"], conv["OH"], conv["OW"]
+        M = conv["B"] * conv["OH"] * conv["OW"]
+    d.M, d.N, d.K = M, N, K
+    d.ldw = wt.shape[1]
+    rows = out_rows if out_rows is not None else M
+    if out is None:
+        out = torch.empty(rows, ldc or N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=DEV)
+        if ldc or remap:
+            out.zero_()
+    d.a, d.wt, d.bias, d.residual, d.out = ptr(a), ptr(wt), ptr(bias), ptr(residual), ptr(out)
+    d.ldc = ldc or N
+    d.ldr = ldr or (residual.shape[-1] if residual is not None else 0)
+    d.out_f32 = 1 if out_f32 else 0
+    d.act = ffi.ACT[act]
+    d.act_after_res = 1 if act_after_res else 0
+    d.res_mod = res_mod
+    if remap:
+        d.remap_in, d.remap_out, d.remap_off = remap
+    if a_scale is not None:
+        d.a_scale = ptr(a_scale)
+        d.rows_per_image = rows_per_image
+    d.tile_hint = tile_hint
+    ffi.check(lib.tfimm_hip_gemm(C.byref(d), stream()), "gemm")
+    return out
+
+
+def layernorm(x, gamma, beta, eps, rows=None, d=None, xs=None, ys=None, out=None):
+    rows = rows if rows is not None else x.shape[0]
+    d = d if d is not None else x.shape[-1]
+    out = out if out is not None else torch.empty(rows, d, dtype=torch.bfloat16, device=DEV)
+    ffi.check(lib.tfimm_hip_layernorm(ptr(x), ptr(out), ptr(gamma), ptr(beta), rows, d, xs or d, ys or d,
+                                      float(eps), stream()), "layernorm")
+    return out
+
+
+def attention(qkv, batch, n_tokens, heads, hd, scale, window=0, shift=0, res=(0, 0), rel_bias=None):
+    out = torch.empty(batch * n_tokens, heads * hd, dtype=torch.bfloat16, device=DEV)
+    d = ffi.AttnDesc()
+    d.qkv, d.out, d.rel_bias = ptr(qkv), ptr(out), ptr(rel_bias)
+    d.batch, d.n_tokens, d.heads, d.hd, d.scale = batch, n_tokens, heads, hd, float(scale)
+    d.window, d.shift, d.res_h, d.res_w = window, shift, res[0], res[1]
+    ffi.check(lib.tfimm_hip_attention(C.byref(d), stream()), "attention")
+    return out
+
+
+def cast_input(x, c_out):
+    B, H, W, Cin = x.shape
+    out = torch.empty(B, H, W, c_out, dtype=torch.bfloat16, device=DEV)
+    ffi.check(lib.tfimm_hip_cast_input(ptr(x), 1 if x.dtype == torch.bfloat16 else 0, ptr(out), B * H * W, Cin,
+                                       c_out, stream()), "cast_input")
+    return out
+
+
+def maxpool(x, k, stride, pad):
+    B, H, W, Cc = x.shape
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = torch.empty(B, OH, OW, Cc, dtype=torch.bfloat16, device=DEV)
+    ffi.check(lib.tfimm_hip_maxpool(ptr(x), ptr(out), B, H, W, Cc, k, stride, pad, OH, OW, stream()), "maxpool")
+    return out
+
+
+def mean_rows(x, out_f32=False):
+    B, R, Cc = x.shape
+    out = torch.empty(B, Cc, dtype=torch.float32 if out_f32 else torch.bfloat16, device=DEV)
+    ffi.check(lib.tfimm_hip_mean_rows(ptr(x), ptr(out), B, R, Cc, 1 if out_f32 else 0, stream()), "mean_rows")
+    return out
+
+
+def bcast_rows(src, dst, B, n_rows, d, dst_rows):
+    ffi.check(lib.tfimm_hip_bcast_rows(ptr(src), ptr(dst), B, n_rows, d, dst_rows, stream()), "bcast_rows")
+    return dst
+
+
+def dwconv(x, w, bias, k, stride, pad_t, pad_l, OH, OW, act="", want_sums=False):
+    B, H, W, Cc = x.shape
+    out = torch.empty(B, OH, OW, Cc, dtype=torch.bfloat16, device=DEV)
+    sums = torch.zeros(B, Cc, dtype=torch.float32, device=DEV) if want_sums else None
+    ffi.check(lib.tfimm_hip_dwconv(ptr(x), ptr(w), ptr(bias), ptr(out), ptr(sums), B, H, W, Cc, k, stride, pad_t,
+                                   pad_l, OH, OW, ffi.ACT[act], stream()), "dwconv")
+    return out, sums
+
+
+def se_gate(sums, inv_count, w1, b1, w2, b2, act, gate_act="sigmoid"):
+    B, Cc = sums.shape
+    rd = w1.shape[0]
+    gate = torch.empty(B, Cc, dtype=torch.float32, device=DEV)
+    ffi.check(lib.tfimm_hip_se_gate(ptr(sums), float(inv_count), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(gate), B, Cc,
+                                    rd, ffi.ACT[act], ffi.ACT[gate_act], stream()), "se_gate")
+    return gate
+
+
+def scale_channels(x, gate, residual=None, relu_after=False):
+    B, R, Cc = x.shape
+    out = torch.empty_like(x)
+    ffi.check(lib.tfimm_hip_scale_channels(ptr(x), ptr(gate), ptr(residual), ptr(out), B, R, Cc,
+                                           1 if relu_after else 0, stream()), "scale_channels")
+    return out
+
+
+def patch_merge_ln(x, gamma, beta, H, W, eps):
+    B, L, Cc = x.shape
+    out = torch.empty(B, (H // 2) * (W // 2), 4 * Cc, dtype=torch.bfloat16, device=DEV)
+    ffi.check(lib.tfimm_hip_patch_merge_ln(ptr(x), ptr(out), ptr(gamma), ptr(beta), B, H, W, Cc, float(eps),
+                                           stream()), "patch_merge_ln")
+    return out

@@ -1,0 +1,54 @@
+"""Model-level parity helpers: HIP engine vs the fp32 CPU oracle on identical inputs/weights.
+
+Bars: the engine stores activations and weights in bf16 and accumulates in
+fp32, the oracle is pure fp32, so the bar is rel-to-max error <= 5e-2 on the logits plus
+top-1 agreement on the synthetic batch (the reference's own fp32-vs-fp32 bar is 1e-3,
+tests/test_timm.py:71).  Weights come from the non-degenerate generator.
+"""
+import numpy as np
+
+import oracle
+import tfimm
+from tfimm.utils.init import synthetic_weights
+
+TOL_LOGITS = 5e-2
+
+
+def make_input(cfg, batch, seed=2021, size=None):
+    """default_rng(2021).random((B,H,W,C)) as in tests/test_timm.py:56-59, then the model's
+    preprocessing ((x - mean) / std on [0, 1) data)."""
+    h, w = size or cfg.input_size
+    x = np.random.default_rng(seed).random((batch, h, w, cfg.in_channels), dtype=np.float32)
+    n = cfg.in_channels
+    mean = np.tile(np.asarray(cfg.mean, np.float32), n // len(cfg.mean) + 1)[:n]
+    std = np.tile(np.asarray(cfg.std, np.float32), n // len(cfg.std) + 1)[:n]
+    std = np.where(std == 0, 1.0, std)
+    return ((x - mean) / std).astype(np.float32)
+
+
+def rel_err(got, ref):
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    if not np.all(np.isfinite(got)):
+        return float("inf")
+    return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-6))
+
+
+def compare_model(name, batch=2, seed=2021, size=None, features=False, **overrides):
+    model = tfimm.create_model(name, **overrides)
+    w = synthetic_weights(model, seed)
+    model.set_weights(w)
+    x = make_input(model.cfg, batch, seed, size)
+    ref = oracle.forward(model.cfg, w, x, return_features=features)
+    got = model(x, return_features=features)
+    out = {}
+    if features:
+        (ref, ref_f), (got, got_f) = ref, got
+        for k in got_f:
+            out["feat:" + k] = rel_err(got_f[k].numpy().reshape(ref_f[k].shape), ref_f[k])
+    g = got.numpy()
+    out["logits"] = rel_err(g.reshape(ref.shape), ref)
+    out["top1_agree"] = float((g.reshape(ref.shape).argmax(-1) == ref.argmax(-1)).mean())
+    out["shape"] = g.shape
+    return out

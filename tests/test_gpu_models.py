@@ -1,0 +1,56 @@
+"""pytest -m gpu: whole-model parity, HIP engine vs fp32 CPU oracle (helpers in model_checks.py)."""
+import numpy as np
+import pytest
+
+import model_checks as mc
+import test_architectures  # noqa: F401  (registers the miniature configs)
+
+pytestmark = pytest.mark.gpu
+
+MINIS = ["vit_test_model", "deit_test_model", "vit_hd64_test_model", "resnet_test_model_1", "resnet_test_model_2",
+         "resnet50_mini_test_model", "seresnet_test_model"]
+FULL = [("vit_tiny_patch16_224", 2), ("deit_tiny_distilled_patch16_224", 2), ("resnet18", 2), ("resnet50", 2),
+        ("vit_base_patch16_224", 1)]
+
+
+@pytest.mark.parametrize("name", MINIS)
+def test_mini_model(name):
+    r = mc.compare_model(name, batch=3)
+    assert r["logits"] <= mc.TOL_LOGITS, r
+
+
+@pytest.mark.parametrize("name,batch", FULL)
+def test_full_model(name, batch):
+    r = mc.compare_model(name, batch=batch)
+    assert r["logits"] <= mc.TOL_LOGITS, r
+    assert r["top1_agree"] == 1.0, r
+
+
+def test_plumbing_vit_tiny_b1():
+    """BASELINE.json configs[0]: vit_tiny_patch16_224, batch 1."""
+    r = mc.compare_model("vit_tiny_patch16_224", batch=1)
+    assert r["shape"] == (1, 1000) and r["logits"] <= mc.TOL_LOGITS, r
+
+
+def test_resnet_other_input_size():
+    """convnets accept any spatial size at inference."""
+    r = mc.compare_model("resnet18", batch=2, size=(160, 128))
+    assert r["logits"] <= mc.TOL_LOGITS, r
+
+
+def test_micro_batch_equals_full_batch():
+    import tfimm
+    from tfimm.utils.init import synthetic_weights
+    m = tfimm.create_model("resnet_test_model_2")
+    m.set_weights(synthetic_weights(m))
+    x = mc.make_input(m.cfg, 5)
+    full = m(x).numpy()
+    m.micro_batch = 2
+    part = m(x).numpy()
+    assert np.array_equal(full, part)
+
+
+def test_features_vit_mini():
+    r = mc.compare_model("vit_test_model", batch=2, features=True)
+    bad = {k: v for k, v in r.items() if k.startswith("feat:") and v > mc.TOL_LOGITS}
+    assert not bad, bad
