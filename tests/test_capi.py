@@ -1,0 +1,54 @@
+"""The C-ABI library loads and exports every symbol include/tfimm_hip.h declares (CPU)."""
+import ctypes
+import os
+import re
+
+from tfimm.engine import ffi
+
+HEADER = os.path.join(os.path.dirname(os.path.dirname(__file__)), "include", "tfimm_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    return sorted(set(re.findall(r"TFIMM_API\s+(?:const\s+)?[\w\*]+\s*\*?\s*(tfimm_hip_\w+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound():
+    names = declared_symbols()
+    assert len(names) >= 15
+    lib = ctypes.CDLL(ffi.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+    assert sorted(ffi.SYMBOLS) == names, "ffi.SYMBOLS and the header disagree"
+
+
+def test_abi_version_and_error_string():
+    assert ffi.lib.tfimm_hip_abi_version() == 1
+    d = ffi.GemmDesc()
+    rc = ffi.lib.tfimm_hip_gemm(ctypes.byref(d), None)
+    assert rc == -1 and b"null" in ffi.lib.tfimm_hip_last_error()
+
+
+def test_descriptor_validation_without_gpu():
+    """bad shapes/alignment are rejected before any launch (no compute needed)."""
+    import torch
+    a = torch.zeros(64, 64, dtype=torch.bfloat16)
+    d = ffi.GemmDesc()
+    d.a = d.wt = d.out = a.data_ptr()
+    d.M = d.N = d.K = 64
+    d.lda = d.ldc = 64
+    d.ldw = 60                                  # < K and not a multiple of 8
+    assert ffi.lib.tfimm_hip_gemm(ctypes.byref(d), None) == -1
+    d.ldw = 64
+    d.mode = 7
+    assert ffi.lib.tfimm_hip_gemm(ctypes.byref(d), None) == -1
+    at = ffi.AttnDesc()
+    at.qkv = at.out = a.data_ptr()
+    at.batch, at.n_tokens, at.heads, at.hd = 1, 16, 1, 128
+    assert ffi.lib.tfimm_hip_attention(ctypes.byref(at), None) == -2      # head dim > 64: not built
+
+
+def test_gemm_desc_layout_matches_header():
+    """size of the ctypes mirrors == the C structs (6 pointers + 28 int32; 3 pointers + 8 int32 + float)."""
+    assert ctypes.sizeof(ffi.GemmDesc) == 6 * 8 + 28 * 4
+    assert ctypes.sizeof(ffi.AttnDesc) == 3 * 8 + 4 * 4 + 4 + 4 * 4 + 4   # 60 + tail padding to 8
