@@ -154,13 +154,26 @@ def run_with_events(plan, x_dev, events):
             ffi.check(rc, f"op {i}")
 
 
+def usable_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup quota
+    (a GPU box reports 256 logical CPUs but the container gets far fewer)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(model, name, target_seconds=20.0):
     """fp32 CPU oracle on a bounded sample of the same workload (non-target number)."""
     import numpy as np
     import torch
     sys.path.insert(0, ROOT)
     import oracle
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     cfg = model.cfg
     b = 8 if cfg.input_size[0] <= 256 else 4

@@ -273,12 +273,11 @@ extern "C" int tfimm_hip_attention(const tfimm_attn_desc* dp, void* stream) {
   const dim3 grid((unsigned)nblocks), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (d.window > 0) {
-    if (d.hd <= 32) hipLaunchKernelGGL((attn_kernel<32, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((attn_kernel<64, true>), grid, block, 0, st, a);
+    if (d.hd <= 32) TFIMM_LAUNCH((attn_kernel<32, true>), grid, block, 0, st, a);
+    else TFIMM_LAUNCH((attn_kernel<64, true>), grid, block, 0, st, a);
   } else {
-    if (d.hd <= 32) hipLaunchKernelGGL((attn_kernel<32, false>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((attn_kernel<64, false>), grid, block, 0, st, a);
+    if (d.hd <= 32) TFIMM_LAUNCH((attn_kernel<32, false>), grid, block, 0, st, a);
+    else TFIMM_LAUNCH((attn_kernel<64, false>), grid, block, 0, st, a);
   }
-  TFIMM_LAUNCH_CHECK();
   return 0;
 }

@@ -28,6 +28,14 @@ void tfimm_set_error(const char* fmt, ...);
     }                                                                              \
   } while (0)
 #define TFIMM_LAUNCH_CHECK() TFIMM_HIP_CHECK(hipGetLastError())
+// hipGetLastError() is sticky per thread: an unrelated earlier failure (e.g. a device probe made
+// by another library before the runtime was initialised) would otherwise be blamed on our launch.
+#define TFIMM_LAUNCH(...)                 \
+  do {                                    \
+    (void)hipGetLastError();              \
+    hipLaunchKernelGGL(__VA_ARGS__);      \
+    TFIMM_LAUNCH_CHECK();                 \
+  } while (0)
 
 // ---- bf16 <-> fp32 -----------------------------------------------------------------
 __device__ __forceinline__ float bf2f(uint32_t h) { return __uint_as_float(h << 16); }

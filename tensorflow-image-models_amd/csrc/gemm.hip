@@ -1,11 +1,16 @@
 // tfimm_hip_gemm host side: descriptor validation, tile selection, launch.
 // Kernel: gemm_kernel.h; per-tile instantiations: gemm_inst.hip.
-#include "gemm_kernel.h"
+#include "gemm_dma_kernel.h"
+
+#include <cstdlib>
 
 using namespace tfimm_gemm;
 
 #define TFIMM_DECL(ID, BM_, BN_, WM_, WN_) extern "C" const TileCfg tfimm_gemm_tile_##ID;
 TFIMM_GEMM_TILES(TFIMM_DECL)
+#undef TFIMM_DECL
+#define TFIMM_DECL(ID, BM_, BN_, WM_, WN_) extern "C" const DmaTileCfg tfimm_gemm_dma_tile_##ID;
+TFIMM_GEMM_DMA_TILES(TFIMM_DECL)
 #undef TFIMM_DECL
 
 namespace {
@@ -15,6 +20,16 @@ const TileCfg* tile_table(int i) {
   case ID: return &tfimm_gemm_tile_##ID;
   switch (i) {
     TFIMM_GEMM_TILES(TFIMM_CASE)
+    default: return nullptr;
+  }
+#undef TFIMM_CASE
+}
+
+const DmaTileCfg* dma_tile_table(int i) {
+#define TFIMM_CASE(ID, BM_, BN_, WM_, WN_) \
+  case ID: return &tfimm_gemm_dma_tile_##ID;
+  switch (i) {
+    TFIMM_GEMM_DMA_TILES(TFIMM_CASE)
     default: return nullptr;
   }
 #undef TFIMM_CASE
@@ -47,6 +62,41 @@ int pick_tile(const tfimm_gemm_desc& d, int kmode) {
   if (N > 64 && blocks(64, 128) >= cus) return 5;
   if (blocks(128, 64) >= 2 * cus) return 1;
   return 2;
+}
+
+// LDS-DMA tile ids: 0 256x256, 1 256x128, 2 128x128, 3 256x64, 4 128x64, 5 128x256.
+// Score = relative kernel efficiency x useful fraction of the padded tile area x fill of the last
+// wave of blocks.  Efficiency weights come from the measured table in DESIGN.md.
+int pick_dma_tile(const tfimm_gemm_desc& d) {
+  if (d.tile_hint > 10 && d.tile_hint <= 10 + TFIMM_GEMM_DMA_NUM_TILES) return d.tile_hint - 11;
+  static const double eff[TFIMM_GEMM_DMA_NUM_TILES] = {1.00, 0.90, 0.70, 0.70, 0.50, 0.90};
+  static const int occ[TFIMM_GEMM_DMA_NUM_TILES] = {1, 1, 2, 1, 3, 1};
+  const int cus = num_cu();
+  int best = 2;
+  double best_score = -1.0;
+  for (int i = 0; i < TFIMM_GEMM_DMA_NUM_TILES; ++i) {
+    const DmaTileCfg* t = dma_tile_table(i);
+    const double tm = (double)cdiv64(d.M, t->bm), tn = (double)cdiv64(d.N, t->bn);
+    const double useful = ((double)d.M * d.N) / (tm * t->bm * tn * t->bn);
+    const double blocks = tm * tn, slots = (double)cus * occ[i];
+    const double waves = (double)cdiv64((int64_t)blocks, (int64_t)slots);
+    const double fill = blocks / (waves * slots);
+    const double score = eff[i] * useful * fill;
+    if (score > best_score) {
+      best_score = score;
+      best = i;
+    }
+  }
+  return best;
+}
+
+bool dma_disabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("TFIMM_GEMM_NO_DMA");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
 }
 
 }  // namespace
@@ -102,10 +152,44 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
     }
   }
   g.res_vec = d.residual ? (((d.ldr & 3) == 0) && (((uintptr_t)d.residual & 7) == 0)) : 0;
+  g.res_vec16 = d.residual ? (((d.ldr & 7) == 0) && (((uintptr_t)d.residual & 15) == 0)) : 0;
+  g.out_vec16 = ((d.ldc & 7) == 0) && (((uintptr_t)d.out & 15) == 0);
   if (d.out_f32)
     g.out_vec = ((d.ldc & 3) == 0) && (((uintptr_t)d.out & 15) == 0);
   else
     g.out_vec = ((d.ldc & 3) == 0) && (((uintptr_t)d.out & 7) == 0);
+
+  // ---- LDS-DMA family: aligned dense rows or Cin % 8 == 0 gathers, weights padded to 64 in k,
+  //      tensors addressable with a 31-bit byte offset
+  {
+    const int64_t a_bytes = (d.mode == TFIMM_A_DENSE) ? ((int64_t)(d.M - 1) * d.lda + d.K) * 2
+                                                       : (int64_t)d.B * d.H * d.W * d.Cin * 2;
+    const int64_t w_bytes = (int64_t)d.N * d.ldw * 2;
+    const bool hint_v1 = d.tile_hint > 0 && d.tile_hint <= TFIMM_GEMM_NUM_TILES;
+    const bool ok = (kmode == K_DENSE || kmode == K_CONV) && !hint_v1 && !dma_disabled() &&
+                    d.ldw >= (int)(cdiv64(d.K, 64) * 64) && a_bytes <= 0x7fffff00LL && w_bytes <= 0x7fffff00LL;
+    if (ok) {
+      const int ti = pick_dma_tile(d);
+      const DmaTileCfg* t = dma_tile_table(ti);
+      GemmDmaArgs ga;
+      ga.g = g;
+      ga.g.tiles_m = (int)cdiv64(d.M, t->bm);
+      ga.g.tiles_n = (int)cdiv64(d.N, t->bn);
+      ga.a_bytes = (unsigned)a_bytes;
+      ga.w_bytes = (unsigned)w_bytes;
+      const int64_t nblocks = (int64_t)ga.g.tiles_m * ga.g.tiles_n;
+      if (nblocks > 0x7fffffffLL) TFIMM_FAIL(TFIMM_EINVAL, "gemm: grid too large");
+      const size_t lds_bytes = (size_t)(t->bm + t->bn) * 128 * 2;
+      gemm_dma_fn fn = t->fn[kmode == K_DENSE ? 0 : 1];
+      static bool dma_attr_done[TFIMM_GEMM_DMA_NUM_TILES][2] = {};
+      if (!dma_attr_done[ti][kmode == K_DENSE ? 0 : 1]) {
+        TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        dma_attr_done[ti][kmode == K_DENSE ? 0 : 1] = true;
+      }
+      TFIMM_LAUNCH(fn, dim3((unsigned)nblocks), dim3(t->threads), lds_bytes, (hipStream_t)stream, ga);
+      return 0;
+    }
+  }
 
   int ti = pick_tile(d, kmode);
   const TileCfg* t = tile_table(ti);
@@ -125,7 +209,6 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
     TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     attr_done[ti][kmode] = true;
   }
-  hipLaunchKernelGGL(fn, dim3((unsigned)nblocks), dim3(t->threads), lds_bytes, (hipStream_t)stream, g);
-  TFIMM_LAUNCH_CHECK();
+  TFIMM_LAUNCH(fn, dim3((unsigned)nblocks), dim3(t->threads), lds_bytes, (hipStream_t)stream, g);
   return 0;
 }

@@ -53,8 +53,10 @@ struct GemmArgs {
   int remap_in, remap_out, remap_off;
   int B, H, W, Cin, KH, KW, KWp, stride, pad_t, pad_l, OH, OW;
   int rows_per_image;
-  int res_vec;  // residual rows can be read as aligned 8-byte quads
-  int out_vec;  // output rows can be written as aligned quads
+  int res_vec;    // residual rows can be read as aligned 8-byte quads
+  int out_vec;    // output rows can be written as aligned quads
+  int res_vec16;  // ... as aligned 16-byte octets (LDS-staged epilogue)
+  int out_vec16;
   int tiles_m, tiles_n;
 };
 

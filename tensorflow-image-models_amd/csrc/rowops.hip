@@ -421,13 +421,12 @@ extern "C" int tfimm_hip_cast_input(const void* in, int in_dtype, void* out, int
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = grid_for(n_pixels, 256);
   if (c_in == 3 && c_out == 4 && (((uintptr_t)out & 7) == 0)) {
-    if (in_dtype) hipLaunchKernelGGL(cast_rgb4_kernel<true>, dim3(grid), dim3(256), 0, st, in, (uint2*)out, n_pixels);
-    else hipLaunchKernelGGL(cast_rgb4_kernel<false>, dim3(grid), dim3(256), 0, st, in, (uint2*)out, n_pixels);
+    if (in_dtype) TFIMM_LAUNCH(cast_rgb4_kernel<true>, dim3(grid), dim3(256), 0, st, in, (uint2*)out, n_pixels);
+    else TFIMM_LAUNCH(cast_rgb4_kernel<false>, dim3(grid), dim3(256), 0, st, in, (uint2*)out, n_pixels);
   } else {
-    if (in_dtype) hipLaunchKernelGGL(cast_input_kernel<true>, dim3(grid), dim3(256), 0, st, in, (bf16_t*)out, n_pixels, c_in, c_out);
-    else hipLaunchKernelGGL(cast_input_kernel<false>, dim3(grid), dim3(256), 0, st, in, (bf16_t*)out, n_pixels, c_in, c_out);
+    if (in_dtype) TFIMM_LAUNCH(cast_input_kernel<true>, dim3(grid), dim3(256), 0, st, in, (bf16_t*)out, n_pixels, c_in, c_out);
+    else TFIMM_LAUNCH(cast_input_kernel<false>, dim3(grid), dim3(256), 0, st, in, (bf16_t*)out, n_pixels, c_in, c_out);
   }
-  TFIMM_LAUNCH_CHECK();
   return 0;
 }
 
@@ -442,14 +441,13 @@ extern "C" int tfimm_hip_layernorm(const void* x, void* y, const float* gamma, c
   const bf16_t* xb = (const bf16_t*)x;
   bf16_t* yb = (bf16_t*)y;
   if (vec) {
-    if (d <= 512) hipLaunchKernelGGL(layernorm_vec_kernel<1>, dim3(grid), dim3(256), 0, st, xb, yb, gamma, beta, rows, d, x_stride, y_stride, eps);
-    else if (d <= 1024) hipLaunchKernelGGL(layernorm_vec_kernel<2>, dim3(grid), dim3(256), 0, st, xb, yb, gamma, beta, rows, d, x_stride, y_stride, eps);
-    else if (d <= 2048) hipLaunchKernelGGL(layernorm_vec_kernel<4>, dim3(grid), dim3(256), 0, st, xb, yb, gamma, beta, rows, d, x_stride, y_stride, eps);
-    else hipLaunchKernelGGL(layernorm_vec_kernel<8>, dim3(grid), dim3(256), 0, st, xb, yb, gamma, beta, rows, d, x_stride, y_stride, eps);
+    if (d <= 512) TFIMM_LAUNCH(layernorm_vec_kernel<1>, dim3(grid), dim3(256), 0, st, xb, yb, gamma, beta, rows, d, x_stride, y_stride, eps);
+    else if (d <= 1024) TFIMM_LAUNCH(layernorm_vec_kernel<2>, dim3(grid), dim3(256), 0, st, xb, yb, gamma, beta, rows, d, x_stride, y_stride, eps);
+    else if (d <= 2048) TFIMM_LAUNCH(layernorm_vec_kernel<4>, dim3(grid), dim3(256), 0, st, xb, yb, gamma, beta, rows, d, x_stride, y_stride, eps);
+    else TFIMM_LAUNCH(layernorm_vec_kernel<8>, dim3(grid), dim3(256), 0, st, xb, yb, gamma, beta, rows, d, x_stride, y_stride, eps);
   } else {
-    hipLaunchKernelGGL(layernorm_generic_kernel, dim3(grid), dim3(256), 0, st, xb, yb, gamma, beta, rows, d, x_stride, y_stride, eps);
+    TFIMM_LAUNCH(layernorm_generic_kernel, dim3(grid), dim3(256), 0, st, xb, yb, gamma, beta, rows, d, x_stride, y_stride, eps);
   }
-  TFIMM_LAUNCH_CHECK();
   return 0;
 }
 
@@ -461,12 +459,11 @@ extern "C" int tfimm_hip_maxpool(const void* x, void* y, int B, int H, int W, in
   const bool vec = (C % 8 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0);
   if (vec) {
     const unsigned grid = grid_for((int64_t)B * OH * OW * (C / 8), 256);
-    hipLaunchKernelGGL(maxpool_vec_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, k, stride, pad, OH, OW);
+    TFIMM_LAUNCH(maxpool_vec_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, k, stride, pad, OH, OW);
   } else {
     const unsigned grid = grid_for((int64_t)B * OH * OW * C, 256);
-    hipLaunchKernelGGL(maxpool_generic_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, k, stride, pad, OH, OW);
+    TFIMM_LAUNCH(maxpool_generic_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, B, H, W, C, k, stride, pad, OH, OW);
   }
-  TFIMM_LAUNCH_CHECK();
   return 0;
 }
 
@@ -474,8 +471,7 @@ extern "C" int tfimm_hip_mean_rows(const void* x, void* y, int B, int R, int C, 
   if (!x || !y || B <= 0 || R <= 0 || C <= 0) TFIMM_FAIL(TFIMM_EINVAL, "mean_rows: bad arguments");
   const int64_t blocks = (int64_t)B * ((C + 63) / 64);
   const unsigned grid = (unsigned)(blocks > 65535 * 16 ? 65535 * 16 : blocks);
-  hipLaunchKernelGGL(mean_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, B, R, C, out_f32);
-  TFIMM_LAUNCH_CHECK();
+  TFIMM_LAUNCH(mean_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, B, R, C, out_f32);
   return 0;
 }
 
@@ -484,8 +480,7 @@ extern "C" int tfimm_hip_bcast_rows(const void* src, void* dst, int B, int n_row
   if (!src || !dst || B <= 0 || n_rows <= 0 || d <= 0 || dst_rows_per_image < n_rows)
     TFIMM_FAIL(TFIMM_EINVAL, "bcast_rows: bad arguments");
   const unsigned grid = grid_for((int64_t)B * n_rows * d, 256);
-  hipLaunchKernelGGL(bcast_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, B, n_rows, d, dst_rows_per_image);
-  TFIMM_LAUNCH_CHECK();
+  TFIMM_LAUNCH(bcast_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, B, n_rows, d, dst_rows_per_image);
   return 0;
 }
 
@@ -499,12 +494,11 @@ extern "C" int tfimm_hip_dwconv(const void* x, const float* w, const float* bias
                    (((uintptr_t)w & 15) == 0);
   if (vec) {
     const unsigned grid = grid_for((int64_t)B * OH * OW * (C / 8), 256);
-    hipLaunchKernelGGL(dwconv_kernel<true>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, w, bias, (bf16_t*)y, sum_out, B, H, W, C, k, stride, pad_t, pad_l, OH, OW, act);
+    TFIMM_LAUNCH(dwconv_kernel<true>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, w, bias, (bf16_t*)y, sum_out, B, H, W, C, k, stride, pad_t, pad_l, OH, OW, act);
   } else {
     const unsigned grid = grid_for((int64_t)B * OH * OW * C, 256);
-    hipLaunchKernelGGL(dwconv_kernel<false>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, w, bias, (bf16_t*)y, sum_out, B, H, W, C, k, stride, pad_t, pad_l, OH, OW, act);
+    TFIMM_LAUNCH(dwconv_kernel<false>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, w, bias, (bf16_t*)y, sum_out, B, H, W, C, k, stride, pad_t, pad_l, OH, OW, act);
   }
-  TFIMM_LAUNCH_CHECK();
   return 0;
 }
 
@@ -514,8 +508,7 @@ extern "C" int tfimm_hip_se_gate(const float* sums, float inv_count, const float
   if (!sums || !w1 || !w2 || !gate || B <= 0 || C <= 0 || rd <= 0) TFIMM_FAIL(TFIMM_EINVAL, "se_gate: bad arguments");
   const size_t lds = (size_t)(C + rd) * sizeof(float);
   if (lds > 64 * 1024) TFIMM_FAIL(TFIMM_EUNSUP, "se_gate: C + rd = %d too large", C + rd);
-  hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, sums, inv_count, w1, b1, w2, b2, gate, C, rd, act, gate_act);
-  TFIMM_LAUNCH_CHECK();
+  TFIMM_LAUNCH(se_gate_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, sums, inv_count, w1, b1, w2, b2, gate, C, rd, act, gate_act);
   return 0;
 }
 
@@ -523,8 +516,7 @@ extern "C" int tfimm_hip_scale_channels(const void* x, const float* gate, const 
                                         int R, int C, int act_after, void* stream) {
   if (!x || !gate || !y || B <= 0 || R <= 0 || C <= 0) TFIMM_FAIL(TFIMM_EINVAL, "scale_channels: bad arguments");
   const unsigned grid = grid_for((int64_t)B * R * C, 256);
-  hipLaunchKernelGGL(scale_channels_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gate, (const bf16_t*)residual, (bf16_t*)y, B, R, C, act_after);
-  TFIMM_LAUNCH_CHECK();
+  TFIMM_LAUNCH(scale_channels_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gate, (const bf16_t*)residual, (bf16_t*)y, B, R, C, act_after);
   return 0;
 }
 
@@ -533,8 +525,7 @@ extern "C" int tfimm_hip_patch_merge_ln(const void* x, void* y, const float* gam
   if (!x || !y || !gamma || !beta || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C <= 0)
     TFIMM_FAIL(TFIMM_EINVAL, "patch_merge_ln: bad arguments");
   const unsigned grid = grid_for((int64_t)B * (H / 2) * (W / 2), 4);
-  hipLaunchKernelGGL(patch_merge_ln_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, gamma, beta, B, H, W, C, eps);
-  TFIMM_LAUNCH_CHECK();
+  TFIMM_LAUNCH(patch_merge_ln_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, gamma, beta, B, H, W, C, eps);
   return 0;
 }
 
@@ -542,7 +533,6 @@ extern "C" int tfimm_hip_bias_act(const void* x, const float* bias, void* y, int
                                   void* stream) {
   if (!x || !y || rows <= 0 || C <= 0) TFIMM_FAIL(TFIMM_EINVAL, "bias_act: bad arguments");
   const unsigned grid = grid_for(rows * C, 256);
-  hipLaunchKernelGGL(bias_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, bias, (bf16_t*)y, rows, C, act);
-  TFIMM_LAUNCH_CHECK();
+  TFIMM_LAUNCH(bias_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, bias, (bf16_t*)y, rows, C, act);
   return 0;
 }

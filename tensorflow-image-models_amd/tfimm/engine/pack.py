@@ -43,9 +43,9 @@ def pad_channels(cin: int) -> int:
 
 
 def pack_matrix(w_nk: np.ndarray) -> np.ndarray:
-    """[N][K] fp32 -> [N][ceil8(K)] bf16 bits."""
+    """[N][K] fp32 -> [N][ceil64(K)] bf16 bits, zero padded."""
     n, k = w_nk.shape
-    out = np.zeros((n, ceil_to(k, 8)), dtype=np.uint16)
+    out = np.zeros((n, ceil_to(k, 64)), dtype=np.uint16)  # 64: one whole LDS-DMA K-tile
     out[:, :k] = to_bf16_bits(w_nk)
     return out
 

@@ -94,10 +94,14 @@ def _gemm_case(M, K, N, *, act="", bias=True, residual=False, act_after_res=Fals
     return _err(got, ref), (TOL_F32 if out_f32 else TOL_BF16)
 
 
-for _t in range(0, 7):
-    CASES[f"gemm_tile{_t}_256x192x320"] = (lambda t=_t: _gemm_case(256, 192, 320, tile=t, seed=1))
-    CASES[f"gemm_tile{_t}_ragged_333x200x150_gelu_res"] = (
+# tile hints: 0 auto, 1..6 register-staged tiles, 11..16 LDS-DMA tiles
+for _t in list(range(0, 7)) + list(range(11, 17)):
+    CASES[f"gemm_tile{_t:02d}_256x192x320"] = (lambda t=_t: _gemm_case(256, 192, 320, tile=t, seed=1))
+    CASES[f"gemm_tile{_t:02d}_ragged_333x200x150_gelu_res"] = (
         lambda t=_t: _gemm_case(333, 200, 150, act="gelu", residual=True, tile=t, seed=2))
+    CASES[f"gemm_tile{_t:02d}_600x320x520_relu_after_res_f32"] = (
+        lambda t=_t: _gemm_case(600, 320, 520, act="relu", residual=True, act_after_res=True, out_f32=True, tile=t,
+                                seed=3))
 CASES["gemm_vit_qkv_394x768x2304"] = lambda: _gemm_case(394, 768, 2304, seed=3)
 CASES["gemm_vit_fc2_394x3072x768_res"] = lambda: _gemm_case(394, 3072, 768, residual=True, seed=4)
 CASES["gemm_head_f32_8x768x1000"] = lambda: _gemm_case(8, 768, 1000, out_f32=True, seed=5)
@@ -199,8 +203,10 @@ CASES["conv3x3_s2_same_even"] = lambda: _conv_case(2, 20, 20, 16, 24, 3, 2, "sam
 CASES["conv3x3_scalar_cin6"] = lambda: _conv_case(2, 8, 8, 6, 10, 3, 1, 1, act="relu", seed=39)
 CASES["conv3x3_scalar_cin2_s2"] = lambda: _conv_case(3, 9, 9, 2, 4, 3, 2, 1, seed=40)
 CASES["conv1ch_8x8_patch"] = lambda: _conv_case(2, 32, 32, 1, 4, 8, 8, 0, bn=False, seed=41)
-for _t in (1, 2, 3, 4, 5, 6):
-    CASES[f"conv3x3_tile{_t}"] = (lambda t=_t: _conv_case(2, 16, 16, 64, 96, 3, 1, 1, act="relu", seed=42, tile=t))
+for _t in (1, 2, 3, 4, 5, 6, 11, 12, 13, 14, 15, 16):
+    CASES[f"conv3x3_tile{_t:02d}"] = (lambda t=_t: _conv_case(2, 16, 16, 64, 96, 3, 1, 1, act="relu", seed=42, tile=t))
+    CASES[f"conv3x3_s2_res_tile{_t:02d}"] = (
+        lambda t=_t: _conv_case(3, 15, 13, 40, 72, 3, 2, 1, act="relu", residual=True, seed=43, tile=t))
 
 
 # ---------------------------------------------------------------------------------------------
