@@ -183,7 +183,7 @@ def cpu_baseline(model, name, target_seconds=20.0):
     t0 = time.perf_counter()
     y = oracle.forward(cfg, w, x)           # warm-up + also the parity sample
     first = time.perf_counter() - t0
-    n = max(1, min(10, int(target_seconds / max(first, 1e-3)) - 1))
+    n = max(1, min(60, int(target_seconds / max(first, 1e-3)) - 1))
     t0 = time.perf_counter()
     for _ in range(n):
         oracle.forward(cfg, w, x)

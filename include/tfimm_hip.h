@@ -215,6 +215,10 @@ TFIMM_API int tfimm_hip_scale_channels(const void* x, const float* gate, const v
 TFIMM_API int tfimm_hip_patch_merge_ln(const void* x, void* y, const float* gamma, const float* beta,
                              int B, int H, int W, int C, float eps, void* stream);
 
+/* hipMemsetAsync on the library's own HIP runtime (zeroing accumulation buffers such as the
+ * dwconv sum_out) -- avoids a second runtime instance being loaded by the host language. */
+TFIMM_API int tfimm_hip_memset_async(void* dst, int value, size_t bytes, void* stream);
+
 /* Elementwise y = act(x + bias?)  -- used by paths with no producer to fuse into. */
 TFIMM_API int tfimm_hip_bias_act(const void* x, const float* bias, void* y, int64_t rows, int C, int act,
                        void* stream);

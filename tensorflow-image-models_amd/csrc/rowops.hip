@@ -529,6 +529,12 @@ extern "C" int tfimm_hip_patch_merge_ln(const void* x, void* y, const float* gam
   return 0;
 }
 
+extern "C" int tfimm_hip_memset_async(void* dst, int value, size_t bytes, void* stream) {
+  if (!dst) TFIMM_FAIL(TFIMM_EINVAL, "memset_async: null pointer");
+  TFIMM_HIP_CHECK(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int tfimm_hip_bias_act(const void* x, const float* bias, void* y, int64_t rows, int C, int act,
                                   void* stream) {
   if (!x || !y || rows <= 0 || C <= 0) TFIMM_FAIL(TFIMM_EINVAL, "bias_act: bad arguments");

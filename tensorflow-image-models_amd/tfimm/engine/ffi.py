@@ -6,6 +6,11 @@ this module raises -- there is deliberately no CPU or PyTorch fallback.
 import ctypes as C
 import os
 
+# torch ships its own libamdhip64/libhsa-runtime64.  It must be loaded FIRST so that
+# libtfimm_hip.so's DT_NEEDED libamdhip64.so.7 resolves to that already-loaded runtime: two HIP
+# runtimes in one process do not share devices/streams (launches fail with hipErrorNoDevice).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtfimm_hip.so")
 
@@ -60,6 +65,7 @@ SYMBOLS = {
     "tfimm_hip_scale_channels": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tfimm_hip_patch_merge_ln": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "tfimm_hip_bias_act": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "tfimm_hip_memset_async": (_i, [_vp, _i, C.c_size_t, _vp]),
 }
 
 

@@ -655,14 +655,6 @@ class Plan:
                 ffi.check(rc, f"op {i} ({getattr(fn, '__name__', fn)})")
 
 
-_hip = None
-
-
 def _hip_memset_async(ptr: int, nbytes: int, stream_ptr: int) -> int:
-    """hipMemsetAsync via the HIP runtime that libtfimm_hip.so is linked against."""
-    global _hip
-    if _hip is None:
-        _hip = C.CDLL("libamdhip64.so")
-        _hip.hipMemsetAsync.restype = C.c_int
-        _hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
-    return _hip.hipMemsetAsync(C.c_void_p(ptr), 0, nbytes, C.c_void_p(stream_ptr))
+    from . import ffi
+    return ffi.lib.tfimm_hip_memset_async(C.c_void_p(ptr), 0, nbytes, C.c_void_p(stream_ptr))

@@ -14,7 +14,7 @@ cat $O/bench.json
 export TMPDIR=/tmp
 for wl in ${PROF_WORKLOADS:-resnet50 vit_base_patch16_224}; do
   cd /tmp
-  timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_$wl -o $wl -- python $R/bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events --extra "" > $O/prof_$wl.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -o $wl -- python $R/bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events --extra "" > $O/prof_$wl.log 2>&1
   echo "rocprof $wl rc=$?"
   f=$(find $O/prof_$wl -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && head -25 "$f"
