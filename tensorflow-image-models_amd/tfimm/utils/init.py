@@ -45,7 +45,7 @@ def initialize(specs, mode: str = "keras", seed: int = 0) -> Dict[str, np.ndarra
                 lim = np.sqrt(6.0 / (fi + fo))
                 w = rng.uniform(-lim, lim, size=shape)
             elif kind in ("gamma", "var"):
-                w = np.ones(shape)
+                w = np.ones(shape)      # also for init == "small" (a hint for the synthetic mode only)
             elif kind == "scale":   # LayerScale: filled with the config's init value
                 w = np.full(shape, float(spec.init or 1e-4))
             else:                   # bias, beta, mean, token, pos, table
@@ -54,7 +54,7 @@ def initialize(specs, mode: str = "keras", seed: int = 0) -> Dict[str, np.ndarra
             if kind in ("conv", "dwconv", "dense"):
                 fi, _ = _fans(shape, kind)
                 w = rng.normal(0.0, np.sqrt(2.0 / fi), size=shape)
-            elif kind == "gamma" and spec.init == "zeros":
+            elif kind == "gamma" and spec.init in ("zeros", "small"):
                 # last BN of a residual branch (zero-initialised in the reference): keep the
                 # branch visible but small so 16-50 stacked blocks stay well conditioned
                 w = rng.uniform(0.1, 0.3, size=shape)

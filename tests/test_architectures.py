@@ -6,11 +6,14 @@ tests/models/architectures.py:33-361: tiny configs registered through the real
 assumptions.  The second block closes coverage holes the survey found in the reference's
 minis: head dim 64, default 7x7 stem + Bottleneck + downsample_conv, SE.
 """
+from tfimm.architectures.efficientnet import EfficientNet, EfficientNetConfig
 from tfimm.architectures.resnet import ResNet, ResNetConfig
+from tfimm.architectures.swin import SwinTransformer, SwinTransformerConfig
 from tfimm.architectures.vit import ViT, ViTConfig
 from tfimm.models import is_model, register_model
 
-TEST_ARCHITECTURES = ["vit_test_model", "deit_test_model", "resnet_test_model_1", "resnet_test_model_2"]
+TEST_ARCHITECTURES = ["efficientnet_test_model", "resnet_test_model_1", "resnet_test_model_2", "swin_test_model",
+                      "vit_test_model", "deit_test_model"]
 
 if not is_model("vit_test_model"):
 
@@ -35,7 +38,36 @@ if not is_model("vit_test_model"):
                                     block="bottleneck", nb_blocks=(1, 1, 1, 1), nb_channels=(2, 4, 6, 8),
                                     first_conv="conv1/0")
 
+    @register_model
+    def swin_test_model():
+        return SwinTransformer, SwinTransformerConfig(name="swin_test_model", nb_classes=12, input_size=(64, 64),
+                                                      patch_size=2, embed_dim=4, nb_blocks=(1, 1, 1, 1),
+                                                      nb_heads=(1, 1, 1, 1), window_size=4)
+
+    @register_model
+    def efficientnet_test_model():
+        return EfficientNet, EfficientNetConfig(
+            name="efficientnet_test_model", input_size=(32, 32),
+            architecture=(("ds_r1_k3_s1_e1_c16_se0.25",), ("ir_r2_k3_s2_e6_c24_se0.25",),
+                          ("er_r1_k3_s1_e4_c24_fc24_noskip",)), nb_features=32)
+
     # ---- repo-owned minis -------------------------------------------------------------------
+    @register_model
+    def swin_shift_test_model():
+        """(2,2,2) blocks so the shifted-window / mask path runs (never executed by the reference's mini)."""
+        return SwinTransformer, SwinTransformerConfig(name="swin_shift_test_model", nb_classes=10, input_size=(64, 32),
+                                                      patch_size=2, embed_dim=16, nb_blocks=(2, 2, 2),
+                                                      nb_heads=(1, 2, 4), window_size=4)
+
+    @register_model
+    def efficientnet_same_test_model():
+        """TF-"same" padding + batch_norm_tf + k5 s2 on an odd resolution (what efficientnet_b4 uses)."""
+        return EfficientNet, EfficientNetConfig(
+            name="efficientnet_same_test_model", nb_classes=10, input_size=(45, 45), stem_size=16,
+            architecture=(("ds_r1_k3_s1_e1_c16_se0.25",), ("ir_r2_k5_s2_e6_c24_se0.25",), ("ir_r2_k3_s2_e4_c40_se0.25",),
+                          ("cn_r1_k3_s1_e1_c40_skip",)),
+            nb_features=64, norm_layer="batch_norm_tf", padding="same")
+
     @register_model
     def vit_hd64_test_model():
         return ViT, ViTConfig(name="vit_hd64_test_model", nb_classes=10, input_size=(48, 48), patch_size=16,

@@ -8,9 +8,11 @@ import test_architectures  # noqa: F401  (registers the miniature configs)
 pytestmark = pytest.mark.gpu
 
 MINIS = ["vit_test_model", "deit_test_model", "vit_hd64_test_model", "resnet_test_model_1", "resnet_test_model_2",
-         "resnet50_mini_test_model", "seresnet_test_model"]
+         "resnet50_mini_test_model", "seresnet_test_model", "swin_test_model", "swin_shift_test_model",
+         "efficientnet_test_model", "efficientnet_same_test_model"]
 FULL = [("vit_tiny_patch16_224", 2), ("deit_tiny_distilled_patch16_224", 2), ("resnet18", 2), ("resnet50", 2),
-        ("vit_base_patch16_224", 1)]
+        ("vit_base_patch16_224", 1), ("swin_tiny_patch4_window7_224", 2), ("efficientnet_b0", 2),
+        ("swin_base_patch4_window7_224", 1), ("efficientnet_b4", 1), ("efficientnet_v2_b0", 2), ("mobilenet_v2_100", 2)]
 
 
 @pytest.mark.parametrize("name", MINIS)

@@ -103,7 +103,8 @@ def model_perf():
     import tfimm
     from tfimm.utils.init import synthetic_weights
     for name, B, mbs in [("vit_base_patch16_224", 512, (None, 128)), ("resnet50", 256, (None, 64, 32)),
-                         ("vit_tiny_patch16_224", 512, (None,))]:
+                         ("vit_tiny_patch16_224", 512, (None,)),
+                         ("swin_base_patch4_window7_224", 256, (None,)), ("efficientnet_b4", 256, (None, 64))]:
         try:
             m = tfimm.create_model(name)
             m.set_weights(synthetic_weights(m))
@@ -144,7 +145,11 @@ if __name__ == "__main__":
                      ("resnet_test_model_1", 3, True), ("resnet_test_model_2", 3, False),
                      ("resnet50_mini_test_model", 3, False), ("seresnet_test_model", 3, False),
                      ("vit_tiny_patch16_224", 2, False), ("resnet18", 2, False), ("resnet50", 2, False),
-                     ("vit_base_patch16_224", 1, False)])
+                     ("vit_base_patch16_224", 1, False), ("swin_test_model", 3, True), ("swin_shift_test_model", 3, True),
+                     ("efficientnet_test_model", 3, True), ("efficientnet_same_test_model", 3, True),
+                     ("swin_tiny_patch4_window7_224", 2, False), ("efficientnet_b0", 2, False),
+                     ("efficientnet_v2_b0", 2, False), ("mobilenet_v2_100", 2, False), ("efficientnet_es", 2, False),
+                     ("swin_base_patch4_window7_224", 1, False), ("efficientnet_b4", 1, False)])
     log(f"SUMMARY op_failures={f1} model_failures={f2}")
     if "--skip-perf" not in sys.argv:
         gemm_perf()
