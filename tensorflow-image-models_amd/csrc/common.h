@@ -39,16 +39,14 @@ void tfimm_set_error(const char* fmt, ...);
 
 // ---- bf16 <-> fp32 -----------------------------------------------------------------
 __device__ __forceinline__ float bf2f(uint32_t h) { return __uint_as_float(h << 16); }
-// round-to-nearest-even, NaN kept quiet
-__device__ __forceinline__ uint32_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return u >> 16;
-}
+// fp32 -> bf16, round-to-nearest-even (hardware v_cvt_pk_bf16_f32 on gfx950; NaN stays NaN)
+typedef __attribute__((ext_vector_type(2))) float tfimm_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 tfimm_bf16x2;
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return f2bf(lo) | (f2bf(hi) << 16);
+  const tfimm_f32x2 f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, tfimm_bf16x2));
 }
+__device__ __forceinline__ uint32_t f2bf(float f) { return pack_bf2(f, 0.f) & 0xffffu; }
 __device__ __forceinline__ void unpack8(const uint4& u, float* f) {
   f[0] = bf2f(u.x & 0xffffu); f[1] = bf2f(u.x >> 16);
   f[2] = bf2f(u.y & 0xffffu); f[3] = bf2f(u.y >> 16);

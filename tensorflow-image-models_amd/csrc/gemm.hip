@@ -1,6 +1,6 @@
 // tfimm_hip_gemm host side: descriptor validation, tile selection, launch.
 // Kernel: gemm_kernel.h; per-tile instantiations: gemm_inst.hip.
-#include "gemm_dma_kernel.h"
+#include "gemm_stream_kernel.h"
 
 #include <cstdlib>
 
@@ -11,6 +11,9 @@ TFIMM_GEMM_TILES(TFIMM_DECL)
 #undef TFIMM_DECL
 #define TFIMM_DECL(ID, BM_, BN_, WM_, WN_) extern "C" const DmaTileCfg tfimm_gemm_dma_tile_##ID;
 TFIMM_GEMM_DMA_TILES(TFIMM_DECL)
+#undef TFIMM_DECL
+#define TFIMM_DECL(ID, BM_, BN_, WM_, WN_) extern "C" const StreamTileCfg tfimm_gemm_stream_tile_##ID;
+TFIMM_GEMM_STREAM_TILES(TFIMM_DECL)
 #undef TFIMM_DECL
 
 namespace {
@@ -30,6 +33,16 @@ const DmaTileCfg* dma_tile_table(int i) {
   case ID: return &tfimm_gemm_dma_tile_##ID;
   switch (i) {
     TFIMM_GEMM_DMA_TILES(TFIMM_CASE)
+    default: return nullptr;
+  }
+#undef TFIMM_CASE
+}
+
+const StreamTileCfg* stream_tile_table(int i) {
+#define TFIMM_CASE(ID, BM_, BN_, WM_, WN_) \
+  case ID: return &tfimm_gemm_stream_tile_##ID;
+  switch (i) {
+    TFIMM_GEMM_STREAM_TILES(TFIMM_CASE)
     default: return nullptr;
   }
 #undef TFIMM_CASE
@@ -88,6 +101,41 @@ int pick_dma_tile(const tfimm_gemm_desc& d) {
     }
   }
   return best;
+}
+
+// Persistent (stream) family: same tile ids as the DMA family.  A persistent grid runs
+// ceil(tiles / slots) rounds; score = efficiency x useful area x fill of those rounds.
+int pick_stream_tile(const tfimm_gemm_desc& d, const int* occ) {
+  if (d.tile_hint > 20 && d.tile_hint <= 20 + TFIMM_GEMM_STREAM_NUM_TILES) return d.tile_hint - 21;
+  static const double eff[TFIMM_GEMM_STREAM_NUM_TILES] = {1.00, 0.90, 0.75, 0.70, 0.55, 0.90};
+  const int cus = num_cu();
+  int best = 2;
+  double best_score = -1.0;
+  for (int i = 0; i < TFIMM_GEMM_STREAM_NUM_TILES; ++i) {
+    const StreamTileCfg* t = stream_tile_table(i);
+    const double tm = (double)cdiv64(d.M, t->bm), tn = (double)cdiv64(d.N, t->bn);
+    const double useful = ((double)d.M * d.N) / (tm * t->bm * tn * t->bn);
+    const double blocks = tm * tn, slots = (double)cus * occ[i];
+    const double rounds = (double)cdiv64((int64_t)blocks, (int64_t)slots);
+    const double fill = blocks / (rounds * slots);
+    const double score = eff[i] * useful * fill;
+    if (score > best_score) {
+      best_score = score;
+      best = i;
+    }
+  }
+  return best;
+}
+
+bool env_flag(const char* name) {
+  const char* e = getenv(name);
+  return e && e[0] == '1';
+}
+
+bool stream_disabled() {
+  static int v = -1;
+  if (v < 0) v = env_flag("TFIMM_GEMM_NO_STREAM") ? 1 : 0;
+  return v == 1;
 }
 
 bool dma_disabled() {
@@ -159,13 +207,70 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
   else
     g.out_vec = ((d.ldc & 3) == 0) && (((uintptr_t)d.out & 7) == 0);
 
+  // ---- persistent LDS-DMA family (default): same operand requirements as the DMA family below
+  {
+    const int64_t a_bytes = (d.mode == TFIMM_A_DENSE) ? ((int64_t)(d.M - 1) * d.lda + d.K) * 2
+                                                       : (int64_t)d.B * d.H * d.W * d.Cin * 2;
+    const int64_t w_bytes = (int64_t)d.N * d.ldw * 2;
+    const bool hinted_other = d.tile_hint > 0 && d.tile_hint <= 20;
+    // extents of the output / residual buffers as the epilogue addresses them (row remap included)
+    const int64_t out_rows = d.remap_in > 0 ? ((int64_t)(d.M - 1) / d.remap_in) * d.remap_out + d.remap_in + d.remap_off : d.M;
+    const int64_t out_bytes = ((out_rows - 1) * d.ldc + d.N) * (d.out_f32 ? 4 : 2);
+    const int64_t res_rows = d.res_mod > 0 ? (d.res_mod < d.M ? d.res_mod : d.M) : d.M;
+    const int64_t res_bytes = d.residual ? ((res_rows - 1) * d.ldr + d.N) * 2 : 0;
+    const bool ok = (kmode == K_DENSE || kmode == K_CONV) && !hinted_other && !stream_disabled() && !dma_disabled() &&
+                    d.ldw >= (int)(cdiv64(d.K, 64) * 64) && a_bytes <= 0x7fffff00LL && w_bytes <= 0x7fffff00LL &&
+                    out_bytes <= 0x7fffff00LL && res_bytes <= 0x7fffff00LL;
+    if (ok) {
+      const int fi = kmode == K_DENSE ? 0 : 1;
+      // vector epilogue: whole 16-byte groups per lane on aligned rows
+      const int vi = ((d.N % 8) == 0 && !d.out_f32 && g.out_vec16 && (!d.residual || g.res_vec16) &&
+                      (d.res_mod == 0 || d.res_mod >= 128) && (d.remap_in == 0 || d.remap_in >= 128)) ? 1 : 0;
+      static int occ[TFIMM_GEMM_STREAM_NUM_TILES][2] = {};
+      static bool ready[2][2] = {{false, false}, {false, false}};
+      if (!ready[fi][vi]) {
+        for (int i = 0; i < TFIMM_GEMM_STREAM_NUM_TILES; ++i) {
+          const StreamTileCfg* t = stream_tile_table(i);
+          TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)t->fn[fi][vi], hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_bytes));
+          int nb = 0;
+          TFIMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)t->fn[fi][vi], t->threads, (size_t)t->lds_bytes));
+          nb = nb < 1 ? 1 : (nb > 4 ? 4 : nb);
+          if (occ[i][fi] == 0 || nb < occ[i][fi]) occ[i][fi] = nb;
+        }
+        ready[fi][vi] = true;
+      }
+      int occ_f[TFIMM_GEMM_STREAM_NUM_TILES];
+      for (int i = 0; i < TFIMM_GEMM_STREAM_NUM_TILES; ++i) occ_f[i] = occ[i][fi];
+      const int ti = pick_stream_tile(d, occ_f);
+      const StreamTileCfg* t = stream_tile_table(ti);
+      GemmStreamArgs ga;
+      ga.g = g;
+      ga.g.tiles_m = (int)cdiv64(d.M, t->bm);
+      ga.g.tiles_n = (int)cdiv64(d.N, t->bn);
+      ga.a_bytes = (unsigned)a_bytes;
+      ga.w_bytes = (unsigned)w_bytes;
+      ga.out_bytes = (unsigned)out_bytes;
+      ga.res_bytes = (unsigned)res_bytes;
+      const int64_t ntiles = (int64_t)ga.g.tiles_m * ga.g.tiles_n;
+      if (ntiles > 0x7fffffffLL) TFIMM_FAIL(TFIMM_EINVAL, "gemm: grid too large");
+      ga.n_tiles = (int)ntiles;
+      ga.cin64 = (kmode == K_CONV && (d.Cin % 64) == 0) ? 1 : 0;
+      int64_t grid = (int64_t)num_cu() * occ_f[ti];
+      grid = (grid + 7) / 8 * 8;
+      const int64_t need = (ntiles + 7) / 8 * 8;
+      if (grid > need) grid = need;
+      TFIMM_LAUNCH(t->fn[fi][vi], dim3((unsigned)grid), dim3(t->threads), (size_t)t->lds_bytes, (hipStream_t)stream, ga);
+      return 0;
+    }
+  }
+
   // ---- LDS-DMA family: aligned dense rows or Cin % 8 == 0 gathers, weights padded to 64 in k,
   //      tensors addressable with a 31-bit byte offset
   {
     const int64_t a_bytes = (d.mode == TFIMM_A_DENSE) ? ((int64_t)(d.M - 1) * d.lda + d.K) * 2
                                                        : (int64_t)d.B * d.H * d.W * d.Cin * 2;
     const int64_t w_bytes = (int64_t)d.N * d.ldw * 2;
-    const bool hint_v1 = d.tile_hint > 0 && d.tile_hint <= TFIMM_GEMM_NUM_TILES;
+    const bool hint_v1 = d.tile_hint > 0 && d.tile_hint <= TFIMM_GEMM_NUM_TILES;  // 11..16 = this family
     const bool ok = (kmode == K_DENSE || kmode == K_CONV) && !hint_v1 && !dma_disabled() &&
                     d.ldw >= (int)(cdiv64(d.K, 64) * 64) && a_bytes <= 0x7fffff00LL && w_bytes <= 0x7fffff00LL;
     if (ok) {

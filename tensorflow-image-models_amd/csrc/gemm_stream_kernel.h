@@ -1,0 +1,489 @@
+// bf16 MFMA GEMM / implicit-GEMM convolution, persistent LDS-DMA variant (gfx950).
+//
+// Same math, operand layouts and fused epilogue as gemm_dma_kernel.h; what changes is the
+// schedule around the K loop:
+//   * PERSISTENT workgroups: the grid is (CUs x resident blocks per CU); each workgroup walks a
+//     strided list of output tiles.  The 8 XCDs own contiguous tile ranges and the workgroups of
+//     one XCD work on neighbouring tiles at any moment, so an activation panel and the weight
+//     panels it meets are pulled through ONE L2.
+//   * the (tile, k-tile) loop is FLATTENED: the LDS-DMA for the next step -- which may be the
+//     first k-tile of the NEXT output tile -- is issued right after the barrier that publishes the
+//     current one.  HBM/L2 latency of a tile's first operands therefore hides under the previous
+//     tile's last MFMAs and its epilogue instead of being exposed once per tile (which is what
+//     made the one-tile-per-workgroup kernel latency-bound on the K <= 256 convolutions of
+//     ResNet/EfficientNet and cost ~30 % on K = 768 ViT GEMMs).
+//   * epilogue per WAVE: a wave stages its 32 x WTN fp32 accumulator block in a private,
+//     XOR-swizzled LDS region and reads it back row-contiguous, so stores / residual loads are
+//     16 B per lane over full 64..128-byte row segments and need no workgroup barrier.  The region
+//     aliases the ring stage that was just consumed when a dedicated one does not fit in 160 KiB
+//     (one extra barrier per tile), otherwise it is separate and a wave's epilogue overlaps the
+//     other waves' MFMAs.
+//   * VMEM operations retire in issue order (one vmcnt for loads AND stores on gfx9), so a load
+//     whose data is needed right behind a store waits for that store's acknowledgement.  The
+//     vector epilogue (VEC = true) is therefore straight-line code over buffer descriptors
+//     (out-of-range lanes get an offset past num_records instead of a branch): bias is loaded at
+//     tile start, residual rows are requested one 32-row pass ahead of their use and BEFORE the
+//     stores of the current pass, and the wait in front of the next tile's first barrier leaves
+//     this tile's stores in flight (counted vmcnt) instead of draining them.
+//   * NHWC gather (K_CONV): when Cin % 64 == 0 every 64-wide k-tile lies inside one filter tap,
+//     so (ky, kx, ci0) is wave-uniform scalar state stepped once per k-tile -- no per-lane
+//     integer divisions in the loop.
+// VEC = false is the catch-all (ragged N, unaligned rows): same main loop, element-wise epilogue
+// loops over the staged block.
+#pragma once
+#include "gemm_dma_kernel.h"
+
+namespace tfimm_gemm {
+
+struct GemmStreamArgs {
+  GemmArgs g;
+  unsigned a_bytes, w_bytes;
+  unsigned out_bytes, res_bytes;   // extents of the output / residual buffers (descriptor bounds)
+  int n_tiles;       // tiles_m * tiles_n
+  int cin64;         // K_CONV: Cin % 64 == 0 (scalar tap stepping)
+};
+
+typedef void (*gemm_stream_fn)(const GemmStreamArgs);
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+struct StreamGeom {
+  static constexpr int NW = WAVES_M * WAVES_N;
+  static constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  static constexpr int EPI_WAVE = 32 * WTN * 4;          // fp32 staging block of one wave
+  static constexpr int EPI_BYTES = NW * EPI_WAVE;
+  static constexpr bool EPI_ALIAS = EPI_BYTES <= STAGE;  // fits inside one ring stage
+  static constexpr int LDS_BYTES = 2 * STAGE + (EPI_ALIAS ? 0 : EPI_BYTES);
+  static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit in LDS");
+};
+
+// Epilogue activation, branch-light (reference act_layer_factory, layers/factory.py:6-13):
+//   clamp class   none / relu / relu6 :   v = min(max(v, lo), hi)                 (always executed)
+//   sigmoid class swish / sigmoid / tanh: s = 1/(1+exp(-k v)); v = a v s + b s + c
+//   gelu (exact erf form; erf by Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7)
+struct ActParams {
+  float lo, hi, k, a, b, c;
+  int cls;
+};
+__device__ __forceinline__ ActParams make_act(int act) {
+  ActParams q;
+  q.lo = -__builtin_inff(); q.hi = __builtin_inff(); q.k = 1.f; q.a = 0.f; q.b = 0.f; q.c = 0.f; q.cls = 0;
+  switch (act) {
+    case TFIMM_ACT_RELU: q.lo = 0.f; break;
+    case TFIMM_ACT_RELU6: q.lo = 0.f; q.hi = 6.f; break;
+    case TFIMM_ACT_SWISH: q.cls = 1; q.a = 1.f; break;
+    case TFIMM_ACT_SIGMOID: q.cls = 1; q.b = 1.f; break;
+    case TFIMM_ACT_TANH: q.cls = 1; q.k = 2.f; q.b = 2.f; q.c = -1.f; break;
+    case TFIMM_ACT_GELU: q.cls = 2; break;
+    default: break;
+  }
+  return q;
+}
+__device__ __forceinline__ float gelu_erf(float v) {
+  const float xx = v * 0.70710678118654752f;
+  const float ax = fabsf(xx);
+  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
+  float poly = 1.061405429f;
+  poly = poly * t - 1.453152027f;
+  poly = poly * t + 1.421413741f;
+  poly = poly * t - 0.284496736f;
+  poly = poly * t + 0.254829592f;
+  const float erfa = 1.f - poly * t * __expf(-ax * ax);
+  return 0.5f * v * (1.f + copysignf(erfa, xx));
+}
+__device__ __forceinline__ float act1(float v, const ActParams& q) {
+  v = fminf(fmaxf(v, q.lo), q.hi);
+  if (q.cls == 1) {
+    const float sgm = __builtin_amdgcn_rcpf(1.f + __expf(-q.k * v));
+    v = q.a * v * sgm + (q.b * sgm + q.c);
+  } else if (q.cls == 2) {
+    v = gelu_erf(v);
+  }
+  return v;
+}
+__device__ __forceinline__ void act8(float* v, const ActParams& q) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(v[e], q.lo), q.hi);
+  if (q.cls == 1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float sgm = __builtin_amdgcn_rcpf(1.f + __expf(-q.k * v[e]));
+      v[e] = q.a * v[e] * sgm + (q.b * sgm + q.c);
+    }
+  } else if (q.cls == 2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KMODE, bool VEC>
+__global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(const GemmStreamArgs pa) {
+  using G = StreamGeom<BM, BN, WAVES_M, WAVES_N>;
+  const GemmArgs& p = pa.g;
+  constexpr int NW = G::NW;
+  constexpr int A_INSTR = BM / 8 / NW;  // 1-KiB DMA instructions per wave per k-tile
+  constexpr int B_INSTR = BN / 8 / NW;
+  constexpr int WTM = G::WTM, WTN = G::WTN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  static_assert(A_INSTR >= 1 && B_INSTR >= 1 && TM >= 1 && TN >= 1, "tile/wave mismatch");
+  static_assert(KMODE == K_DENSE || KMODE == K_CONV, "LDS-DMA flavours: dense rows or Cin % 8 == 0 gather");
+  static_assert(WTN == 32 || WTN == 64, "epilogue swizzle is written for 32/64-wide wave tiles");
+  constexpr int A_BYTES = G::A_BYTES, STAGE = G::STAGE;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // ---- this workgroup's tile list: XCD x owns tiles [t_lo, t_hi); its workgroups stride through it
+  int t_first, t_hi, t_step;
+  {
+    const int nb = gridDim.x;             // multiple of 8 (host)
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, j = bid >> 3;
+    const int q = pa.n_tiles >> 3, r = pa.n_tiles & 7;
+    const int t_lo = xcd * q + (xcd < r ? xcd : r);
+    t_hi = t_lo + q + (xcd < r ? 1 : 0);
+    t_step = nb >> 3;
+    t_first = t_lo + j;
+  }
+  if (t_first >= t_hi) return;
+
+  const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(p.a, pa.a_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(p.wt, pa.w_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_o = make_rsrc(p.out, pa.out_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_r = make_rsrc(p.residual, pa.res_bytes);
+
+  const int nk = (p.K + BK - 1) / BK;
+  const int lrow = lane >> 3;   // row within an 8-row DMA piece
+  const int lpc = lane & 7;     // physical 16-byte chunk this lane fills
+
+  // ---- DMA source state of the tile being ISSUED (one step ahead of the tile being computed)
+  unsigned a_off[A_INSTR];      // dense: byte offset of (row, chunk) at k = 0, or kOobOffset
+  int a_iy0[A_INSTR], a_ix0[A_INSTR], a_pix[A_INSTR];
+  unsigned b_off[B_INSTR];
+  int s_ky = 0, s_kx = 0, s_ci0 = 0;   // K_CONV + cin64: wave-uniform tap state of the next k-tile
+
+  auto a_chunk = [&](int j) -> int {    // logical 16-byte k-chunk this lane fetches for DMA piece j
+    const int r = (wave * A_INSTR + j) * 8 + lrow;
+    return lpc ^ ((r >> 1) & 7);
+  };
+
+  // `valid` false (no further tile for this workgroup): every offset out of range, the DMA that is
+  // still issued unconditionally then only writes zeros -- keeps the K loop free of VMEM branches
+  auto setup_issue = [&](int tile, bool valid) __attribute__((always_inline)) {
+    const int mt = tile / p.tiles_n, nt = tile - mt * p.tiles_n;
+    const int m0 = mt * BM, n0 = nt * BN;
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+      const int r = (wave * A_INSTR + j) * 8 + lrow;
+      const int m = m0 + r;
+      const bool ok = valid && m < p.M;
+      if (KMODE == K_DENSE) {
+        a_off[j] = ok ? (unsigned)(((size_t)m * p.lda + a_chunk(j) * 8) * 2) : kOobOffset;
+        a_iy0[j] = a_ix0[j] = a_pix[j] = 0;
+      } else {
+        const int mm = ok ? m : 0;
+        const int ohw = p.OH * p.OW;
+        const int b = mm / ohw;
+        const int rem = mm - b * ohw;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        a_iy0[j] = ok ? oy * p.stride - p.pad_t : -(1 << 28);
+        a_ix0[j] = ox * p.stride - p.pad_l;
+        a_pix[j] = b * p.H * p.W;
+        a_off[j] = 0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) {
+      const int r = (wave * B_INSTR + j) * 8 + lrow;
+      const int chunk = lpc ^ ((r >> 1) & 7);
+      const int n = n0 + r;
+      b_off[j] = (valid && n < p.N) ? (unsigned)(((size_t)n * p.ldw + chunk * 8) * 2) : kOobOffset;
+    }
+    s_ky = s_kx = s_ci0 = 0;
+  };
+
+  auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+    char* sa = smem + stage * STAGE;
+    char* sb = sa + A_BYTES;
+    const int kbytes = kt * 128;
+    // B (weights): rows are zero padded to a multiple of 64 -> always in range in k
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(sb + (wave * B_INSTR + j) * 1024), 16,
+                                               (int)b_off[j], kbytes, 0, 0);
+    }
+    if (KMODE == K_DENSE) {
+#pragma unroll
+      for (int j = 0; j < A_INSTR; ++j) {
+        const bool kok = (kt * BK + a_chunk(j) * 8) < p.K;
+        const unsigned off = kok ? a_off[j] : kOobOffset;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sa + (wave * A_INSTR + j) * 1024), 16,
+                                                 (int)off, kbytes, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < A_INSTR; ++j) {
+        int ky, kx, ci;
+        bool kok = true;
+        if (pa.cin64) {   // whole k-tile inside tap (s_ky, s_kx), channels s_ci0 .. s_ci0 + 63
+          ky = s_ky; kx = s_kx; ci = s_ci0 + a_chunk(j) * 8;
+        } else {
+          const int kg = kt * BK + a_chunk(j) * 8;
+          const int tap = kg / p.Cin;
+          ci = kg - tap * p.Cin;
+          ky = tap / p.KW; kx = tap - ky * p.KW;
+          kok = kg < p.K;
+        }
+        const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+        const bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const unsigned off = ok ? (unsigned)((((size_t)(a_pix[j] + iy * p.W + ix)) * p.Cin + ci) * 2) : kOobOffset;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sa + (wave * A_INSTR + j) * 1024), 16,
+                                                 (int)off, 0, 0, 0);
+      }
+      if (pa.cin64) {
+        s_ci0 += BK;
+        if (s_ci0 >= p.Cin) {
+          s_ci0 = 0;
+          if (++s_kx == p.KW) { s_kx = 0; ++s_ky; }
+        }
+      }
+    }
+  };
+
+  const int frow = lane & 31;
+  const int fhi = lane >> 5;
+
+  // epilogue staging block of this wave
+  constexpr int SLOTS = WTN / 4;                  // 16-byte slots per staged row
+  constexpr int LPR = WTN / 8;                    // lanes per row at read-back (8 outputs each)
+  constexpr int RPI = 64 / LPR;                   // rows per read-back iteration
+  constexpr int ITS = 32 / RPI;                   // read-back iterations per 32-row pass
+  auto epi_slot = [](int row, int slot) -> int {  // physical slot (conflict-free b128 writes and reads)
+    return SLOTS == 16 ? (slot ^ (row & 15)) : (slot ^ ((row >> 1) & 7));
+  };
+  const ActParams actp = make_act(p.act);
+  const int e_row = lane / LPR;
+  const int e_c8 = lane % LPR;
+  const bool has_res = p.residual != nullptr;
+
+  // ---- prime the pipeline
+  int iss_tile = t_first, iss_kt = 1;
+  setup_issue(iss_tile, true);
+  issue(0, 0);
+  int cur = 0;
+  bool stores_pending = false;   // the previous step ended an interior tile: its stores may still be in flight
+
+  for (int tile = t_first; tile < t_hi; tile += t_step) {
+    const int mt = tile / p.tiles_n, nt = tile - mt * p.tiles_n;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+    const int e_n = n0 + wn * WTN + e_c8 * 8;        // first of this lane's 8 output channels
+    const int e_m = m0 + wm * WTM + e_row;           // output row at (pass 0, iteration 0)
+
+    float bias8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+    if (VEC && p.bias) {
+      if (e_n + 7 < p.N) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + e_n);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + e_n + 4);
+        bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
+        bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+      }
+    }
+
+    // VEC: rows advance by compile-time steps d = i * 32 + it * RPI < 128 from e_m, so the modulo of
+    // res_mod (residual broadcast over images, e.g. pos_embed) and the div/mod of the row remap
+    // (patch rows -> token rows) are done ONCE per tile and stepped with one conditional wrap each
+    // (host guarantees res_mod, remap_in are 0 or >= 128 for this flavour).
+    const int resmod_eff = p.res_mod > 0 ? p.res_mod : 0x7fffffff;
+    const int remap_eff = p.remap_in > 0 ? p.remap_in : 0x7fffffff;
+    const int rm0 = p.res_mod > 0 ? e_m % p.res_mod : e_m;
+    const int oq0 = p.remap_in > 0 ? e_m / p.remap_in : 0;
+    const int or0 = p.remap_in > 0 ? e_m - oq0 * p.remap_in : e_m;
+    const int ooff = p.remap_in > 0 ? p.remap_off : 0;
+    // residual row of (pass i, iteration it).  Issued unconditionally: without a residual the
+    // descriptor has zero records and every lane reads 0 -- no branch, so hipcc's vmcnt
+    // bookkeeping through the epilogue stays exact.
+    uint4 rres[ITS];
+    auto load_res1 = [&](int i, int it) __attribute__((always_inline)) {
+      const int d = i * 32 + it * RPI;
+      int rm = rm0 + d;
+      rm -= rm >= resmod_eff ? resmod_eff : 0;
+      const unsigned off = (e_m + d < p.M && e_n < p.N) ? (unsigned)(((size_t)rm * p.ldr + e_n) * 2) : kOobOffset;
+      rres[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, (int)off, 0, 0));
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // one step of the flattened (tile, k-tile) pipeline; `last` = final k-tile of this tile
+    auto kstep = [&](bool last) __attribute__((always_inline)) {
+      // This wave's DMA pieces of the current step must have landed.  VMEM operations retire in
+      // issue order, and the only ones younger than that DMA are the previous tile's epilogue
+      // (>= TM*ITS store instructions for an interior tile): leave exactly those in flight.
+      if (VEC && stores_pending) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TM * ITS) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      stores_pending = false;
+      __builtin_amdgcn_s_barrier();                      // ... everyone's; stage cur^1 (and an aliased
+      asm volatile("" ::: "memory");                     //     epilogue block in it) is free again
+      // first residual rows of THIS tile: requested ahead of the next step's DMA, so the wait for
+      // them in the epilogue leaves that DMA in flight
+      if (VEC && last) {
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) load_res1(0, it);
+      }
+      // issue the next step: next k-tile of this tile, or k-tile 0 of this workgroup's next tile
+      if (iss_kt == nk) {
+        iss_tile += t_step;
+        iss_kt = 0;
+        setup_issue(iss_tile, iss_tile < t_hi);
+      }
+      issue(iss_kt, cur ^ 1);
+      ++iss_kt;
+
+      const uint4* sA = reinterpret_cast<const uint4*>(smem + cur * STAGE);
+      const uint4* sB = reinterpret_cast<const uint4*>(smem + cur * STAGE + A_BYTES);
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          fa[i] = __builtin_bit_cast(bf16x8, sA[lds_slot(wm * WTM + i * 32 + frow, ks * 2 + fhi)]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          fb[j] = __builtin_bit_cast(bf16x8, sB[lds_slot(wn * WTN + j * 32 + frow, ks * 2 + fhi)]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      }
+      cur ^= 1;
+    };
+
+    for (int kt = 0; kt + 1 < nk; ++kt) kstep(false);
+    kstep(true);
+
+    // ---- epilogue (per wave).  Aliased staging lives in the stage consumed last (index cur^1 now):
+    //      wait until every wave is done reading it; the next refill of that stage is issued only
+    //      after the next step's barrier, i.e. after every wave finished this epilogue.
+    float* sEw;
+    if (G::EPI_ALIAS) {
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      sEw = reinterpret_cast<float*>(smem + (cur ^ 1) * STAGE + wave * G::EPI_WAVE);
+    } else {
+      sEw = reinterpret_cast<float*>(smem + 2 * STAGE + wave * G::EPI_WAVE);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      // The staging stores below are inline asm, and hipcc pads no hazards inside or in front of an
+      // asm statement: an MFMA result needs up to 18 wait states before a DS instruction may read it
+      // (XDL write VGPR -> LDS read, 16-pass case).  Naming this pass's accumulators as operands
+      // orders the pad behind the MFMAs that produce them.
+      if (TN == 2) {
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[i][0]), "+v"(acc[i][TN - 1]));
+      } else {
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[i][0]));
+      }
+      // lane holds output row (frow) x 4 consecutive channels per accumulator quad
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int slot = j * 8 + q * 2 + fhi;
+          const f32x4 v = {acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+          // Written with an explicit ds_write: hipcc orders every LDS store it can see behind ALL
+          // outstanding LDS-DMA (s_waitcnt vmcnt(0)), which would drain the next step's prefetch at
+          // every epilogue.  The staging block never overlaps the stage that DMA is filling, and
+          // DS operations of one wave execute in order, so the read-back below needs no wait.
+          const unsigned addr = (unsigned)(size_t)(lds_ptr_t)(&sEw[frow * WTN + epi_slot(frow, slot) * 4]);
+          asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+        }
+      if (VEC) {
+        // read back row-contiguous: lane handles 8 consecutive channels of one row
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+          const int pr = it * RPI + e_row;
+          const int m = e_m + i * 32 + it * RPI;
+          const float4 lo = *reinterpret_cast<const float4*>(&sEw[pr * WTN + epi_slot(pr, 2 * e_c8) * 4]);
+          const float4 hi = *reinterpret_cast<const float4*>(&sEw[pr * WTN + epi_slot(pr, 2 * e_c8 + 1) * 4]);
+          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+          float r8[8];
+          unpack8(rres[it], r8);
+          // the next pass's row for this slot: requested before this iteration's store and consumed
+          // a pass later, so its return never sits behind a store acknowledgement
+          if (i + 1 < TM) load_res1(i + 1, it);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += p.act_after_res ? r8[e] : 0.f;
+          act8(v, actp);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += p.act_after_res ? 0.f : r8[e];
+          const int d = i * 32 + it * RPI;
+          int orr = or0 + d, oq = oq0;
+          if (orr >= remap_eff) { orr -= remap_eff; ++oq; }
+          const int om = oq * p.remap_out + orr + ooff;
+          const unsigned off = (m < p.M && e_n < p.N) ? (unsigned)(((size_t)om * p.ldc + e_n) * 2) : kOobOffset;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pack8(v)), rsrc_o, (int)off, 0, 0);
+        }
+      } else {
+        // catch-all: element loop over the staged block (the wave's own LDS, in order -> no barrier)
+        for (int idx = lane; idx < 32 * WTN; idx += 64) {
+          const int pr = idx / WTN, c = idx - pr * WTN;
+          const int m = m0 + wm * WTM + i * 32 + pr, n = n0 + wn * WTN + c;
+          if (m < p.M && n < p.N) {
+            float v = sEw[pr * WTN + epi_slot(pr, c >> 2) * 4 + (c & 3)];
+            if (p.bias) v += p.bias[n];
+            float r = 0.f;
+            if (has_res) {
+              const int rm = p.res_mod > 0 ? (m % p.res_mod) : m;
+              r = bf2f(p.residual[(size_t)rm * p.ldr + n]);
+            }
+            if (p.act_after_res) v += r;
+            v = act1(v, actp);
+            if (!p.act_after_res) v += r;
+            const int om = p.remap_in > 0 ? (m / p.remap_in) * p.remap_out + (m % p.remap_in) + p.remap_off : m;
+            if (p.out_f32) reinterpret_cast<float*>(p.out)[(size_t)om * p.ldc + n] = v;
+            else reinterpret_cast<bf16_t*>(p.out)[(size_t)om * p.ldc + n] = (bf16_t)f2bf(v);
+          }
+        }
+      }
+    }
+    stores_pending = VEC && interior;
+  }
+  // the last step's (all out-of-range) prefetch must have landed before this workgroup's LDS is released
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+struct StreamTileCfg {
+  int bm, bn, threads, lds_bytes;
+  gemm_stream_fn fn[2][2];  // [K_DENSE, K_CONV][catch-all, VEC]
+};
+
+}  // namespace tfimm_gemm
+
+// persistent tile shapes: id, BM, BN, WAVES_M, WAVES_N
+#define TFIMM_GEMM_STREAM_TILES(X) \
+  X(0, 256, 256, 2, 4)             \
+  X(1, 256, 128, 4, 2)             \
+  X(2, 128, 128, 2, 2)             \
+  X(3, 256, 64, 4, 2)              \
+  X(4, 128, 64, 2, 2)              \
+  X(5, 128, 256, 2, 4)
+#define TFIMM_GEMM_STREAM_NUM_TILES 6

@@ -320,6 +320,119 @@ __global__ void __launch_bounds__(256) dwconv_kernel(const bf16_t* x, const floa
   }
 }
 
+// Strip kernel (C % 8 == 0, k/stride known at compile time): a thread owns 8 channels x PX
+// horizontally adjacent output pixels.  Per filter row it loads each needed input column ONCE
+// (16 B) and feeds every (pixel, tap) pair that touches it, with that row's weights held in
+// registers -- k*k/PX-fold fewer loads than one-output-per-thread.  Consecutive lanes own
+// consecutive channel groups, so every load/store instruction covers contiguous NHWC bytes.
+// The SE squeeze (sum of the stored, bf16-rounded outputs per image and channel) is reduced in
+// LDS ([8][C/8], conflict-free ds_add) and leaves the block as ONE global atomic per channel.
+template <int K, int S, int PX>
+__global__ void __launch_bounds__(256) dwconv_strip_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, bf16_t* __restrict__ y,
+                                                           float* sum_out, int H, int W, int C, int pad_t, int pad_l,
+                                                           int OH, int OW, int act) {
+  extern __shared__ float lsum[];  // [8][cgs]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int cgs = C >> 3;
+  const int sx = (OW + PX - 1) / PX;
+  const int items = OH * sx * cgs;
+  if (sum_out) {
+    for (int i = tid; i < 8 * cgs; i += 256) lsum[i] = 0.f;
+    __syncthreads();
+  }
+  constexpr int COLS = (PX - 1) * S + K;
+  for (int item = blockIdx.x * 256 + tid; item < items; item += gridDim.x * 256) {
+    const int cg = item % cgs;
+    const int t = item / cgs;
+    const int sxi = t % sx, oy = t / sx;
+    const int ox0 = sxi * PX, c0 = cg * 8;
+    float acc[PX][8];
+    {
+      float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + c0);
+        const float4 b1 = *reinterpret_cast<const float4*>(bias + c0 + 4);
+        b8[0] = b0.x; b8[1] = b0.y; b8[2] = b0.z; b8[3] = b0.w; b8[4] = b1.x; b8[5] = b1.y; b8[6] = b1.z; b8[7] = b1.w;
+      }
+#pragma unroll
+      for (int px = 0; px < PX; ++px)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[px][e] = b8[e];
+    }
+    const int ixb = ox0 * S - pad_l;
+#pragma unroll 1
+    for (int ky = 0; ky < K; ++ky) {
+      const int iy = oy * S - pad_t + ky;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      float wr[K][8];
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const float* wp = w + (size_t)(ky * K + kx) * C + c0;
+        const float4 w0 = *reinterpret_cast<const float4*>(wp);
+        const float4 w1 = *reinterpret_cast<const float4*>(wp + 4);
+        wr[kx][0] = w0.x; wr[kx][1] = w0.y; wr[kx][2] = w0.z; wr[kx][3] = w0.w;
+        wr[kx][4] = w1.x; wr[kx][5] = w1.y; wr[kx][6] = w1.z; wr[kx][7] = w1.w;
+      }
+      const bf16_t* xrow = x + ((size_t)((size_t)b * H + iy) * W) * C + c0;
+#pragma unroll
+      for (int col = 0; col < COLS; ++col) {
+        const int ix = ixb + col;
+        if ((unsigned)ix < (unsigned)W) {
+          float v[8];
+          unpack8(*reinterpret_cast<const uint4*>(xrow + (size_t)ix * C), v);
+#pragma unroll
+          for (int px = 0; px < PX; ++px) {
+            const int kx = col - px * S;   // compile-time after unrolling
+            if (kx >= 0 && kx < K) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) acc[px][e] += v[e] * wr[kx][e];
+            }
+          }
+        }
+      }
+    }
+    float tot[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bf16_t* yrow = y + ((size_t)((size_t)b * OH + oy) * OW) * C + c0;
+#pragma unroll
+    for (int px = 0; px < PX; ++px) {
+      if (ox0 + px < OW) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[px][e] = apply_act(acc[px][e], act);
+        const uint4 u = pack8(acc[px]);
+        *reinterpret_cast<uint4*>(yrow + (size_t)(ox0 + px) * C) = u;
+        float r[8];
+        unpack8(u, r);  // the squeeze sees the stored (bf16-rounded) activations
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tot[e] += r[e];
+      }
+    }
+    if (sum_out) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(&lsum[e * cgs + cg], tot[e]);
+    }
+  }
+  if (sum_out) {
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) atomicAdd(sum_out + (size_t)b * C + c, lsum[(c & 7) * cgs + (c >> 3)]);
+  }
+}
+
+template <int K, int S>
+static int launch_dwconv_strip(const bf16_t* x, const float* w, const float* bias, bf16_t* y, float* sum_out, int B,
+                               int H, int W, int C, int pad_t, int pad_l, int OH, int OW, int act, hipStream_t st) {
+  constexpr int PX = 4;
+  const int64_t items = (int64_t)OH * ((OW + PX - 1) / PX) * (C / 8);
+  int64_t bpi = (items + 255) / 256;                    // blocks per image if every thread took one item
+  const int64_t want = (8 * 256 + B - 1) / B;           // ~8 resident blocks per CU over the whole grid
+  if (bpi > want) bpi = want < 1 ? 1 : want;
+  const size_t lds = sum_out ? (size_t)C * sizeof(float) : 0;
+  TFIMM_LAUNCH((dwconv_strip_kernel<K, S, PX>), dim3((unsigned)bpi, (unsigned)B), dim3(256), lds, st, x, w, bias, y,
+               sum_out, H, W, C, pad_t, pad_l, OH, OW, act);
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // SE gate: one block per image
 // ---------------------------------------------------------------------------------------
@@ -492,6 +605,15 @@ extern "C" int tfimm_hip_dwconv(const void* x, const float* w, const float* bias
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (C % 8 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0) &&
                    (((uintptr_t)w & 15) == 0);
+  if (vec && C <= 8192 && B <= 65535) {
+    const bf16_t* xb = (const bf16_t*)x;
+    bf16_t* yb = (bf16_t*)y;
+    if (k == 3 && stride == 1) return launch_dwconv_strip<3, 1>(xb, w, bias, yb, sum_out, B, H, W, C, pad_t, pad_l, OH, OW, act, st);
+    if (k == 3 && stride == 2) return launch_dwconv_strip<3, 2>(xb, w, bias, yb, sum_out, B, H, W, C, pad_t, pad_l, OH, OW, act, st);
+    if (k == 5 && stride == 1) return launch_dwconv_strip<5, 1>(xb, w, bias, yb, sum_out, B, H, W, C, pad_t, pad_l, OH, OW, act, st);
+    if (k == 5 && stride == 2) return launch_dwconv_strip<5, 2>(xb, w, bias, yb, sum_out, B, H, W, C, pad_t, pad_l, OH, OW, act, st);
+    if (k == 7 && stride == 1) return launch_dwconv_strip<7, 1>(xb, w, bias, yb, sum_out, B, H, W, C, pad_t, pad_l, OH, OW, act, st);
+  }
   if (vec) {
     const unsigned grid = grid_for((int64_t)B * OH * OW * (C / 8), 256);
     TFIMM_LAUNCH(dwconv_kernel<true>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, w, bias, (bf16_t*)y, sum_out, B, H, W, C, k, stride, pad_t, pad_l, OH, OW, act);

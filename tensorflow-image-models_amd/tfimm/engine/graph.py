@@ -17,7 +17,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 import numpy as np
 
 from ..utils.etc import same_padding
-from . import pack
+from . import pack, tune
 
 
 # ---------------------------------------------------------------------------------------
@@ -487,7 +487,10 @@ class Plan:
         self._keepalive = []
         self.calls: List[Tuple[Callable, tuple]] = []
         self._input_patch = None
+        self._gemm_descs = []
         self._build()
+        if device != "cpu" and tune.autotune_enabled():
+            self.autotune()
 
     # pointers ----------------------------------------------------------------------------------
     def tptr(self, tid: int) -> int:
@@ -558,7 +561,9 @@ class Plan:
                     d.rows_per_image = a["a_rows_per_image"]
                 if a.get("remap"):
                     d.remap_in, d.remap_out, d.remap_off = a["remap"]
+                d.tile_hint = tune.lookup(d)
                 self._keepalive.append(d)
+                self._gemm_descs.append(d)
                 self.calls.append((lib.tfimm_hip_gemm, (C.byref(d),)))
             elif k == "layernorm":
                 xp = self.tptr(op.inputs[0]) + a["x_byte_offset"]
@@ -612,6 +617,40 @@ class Plan:
                                     self.cptr(op.consts["beta"]), B, a["H"], a["W"], a["C"], a["eps"])))
             else:
                 raise NotImplementedError(k)
+
+    def autotune(self, iters: int = 3, verbose: bool = False) -> int:
+        """Time every GEMM launch of this plan with each tile shape of the LDS-DMA families (on the
+        plan's own buffers) and keep the fastest (tfimm_gemm_desc.tile_hint).  Results are cached
+        per problem shape in ``tune`` for later plans.  Returns the number of shapes tuned."""
+        import torch
+        lib = self.ffi.lib
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        tuned = 0
+        for d in self._gemm_descs:
+            key = tune.key_of(d)
+            if key in tune.TABLE:
+                d.tile_hint = tune.TABLE[key]
+                continue
+            best, best_ms = 0, float("inf")
+            for hint in tune.CANDIDATES:
+                d.tile_hint = hint
+                if lib.tfimm_hip_gemm(C.byref(d), st) != 0:
+                    continue
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters):
+                    lib.tfimm_hip_gemm(C.byref(d), st)
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1) / iters
+                if verbose:
+                    print(f"tune {key} hint={hint} {ms * 1e3:.1f} us")
+                if ms < best_ms:
+                    best, best_ms = hint, ms
+            tune.TABLE[key] = best
+            d.tile_hint = best
+            tuned += 1
+        return tuned
 
     def check_marshalling(self):
         """Convert every recorded argument through the ctypes prototypes (no launch): catches

@@ -1,0 +1,56 @@
+"""GEMM tile selection table.
+
+``tfimm_hip_gemm`` picks a tile shape with a static cost model unless the descriptor carries a
+``tile_hint``.  This module keeps a table ``problem shape -> tile_hint`` that is
+  * loaded from ``gemm_tune.json`` next to this file (measured on an MI355X by
+    ``tools/tune_gemm.py``; committed so that runs are reproducible), and
+  * extended at plan-build time when autotuning is on (``TFIMM_AUTOTUNE=1`` or
+    ``tune.enable_autotune()``): ``Plan.autotune`` times every candidate on the plan's own
+    buffers before the first forward.
+Hints: 0 = library cost model, 11..16 = one-tile-per-workgroup LDS-DMA tiles, 21..26 =
+persistent LDS-DMA tiles (ids: 256x256, 256x128, 128x128, 256x64, 128x64, 128x256).
+"""
+import json
+import os
+
+_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tune.json")
+CANDIDATES = (0, 21, 22, 23, 24, 25, 26, 11, 12, 13, 14, 15, 16)
+TABLE = {}
+_autotune = os.environ.get("TFIMM_AUTOTUNE", "0") == "1"
+
+
+def enable_autotune(on: bool = True):
+    global _autotune
+    _autotune = bool(on)
+
+
+def autotune_enabled() -> bool:
+    return _autotune
+
+
+def key_of(d) -> str:
+    """Everything that changes the kernel's work: GEMM extents, operand strides, conv geometry and
+    the epilogue flavour (residual / fp32 output change the epilogue's memory traffic)."""
+    return ":".join(str(int(v)) for v in (
+        d.mode, d.M, d.N, d.K, d.lda, d.ldc, d.H, d.W, d.Cin, d.KH, d.KW, d.stride,
+        1 if d.residual else 0, d.out_f32, d.act))
+
+
+def lookup(d) -> int:
+    return TABLE.get(key_of(d), 0)
+
+
+def load(path: str = _PATH) -> int:
+    if not os.path.exists(path):
+        return 0
+    with open(path) as f:
+        TABLE.update({k: int(v) for k, v in json.load(f).items()})
+    return len(TABLE)
+
+
+def save(path: str = _PATH):
+    with open(path, "w") as f:
+        json.dump(dict(sorted(TABLE.items())), f, indent=0)
+
+
+load()

@@ -94,14 +94,19 @@ def _gemm_case(M, K, N, *, act="", bias=True, residual=False, act_after_res=Fals
     return _err(got, ref), (TOL_F32 if out_f32 else TOL_BF16)
 
 
-# tile hints: 0 auto, 1..6 register-staged tiles, 11..16 LDS-DMA tiles
-for _t in list(range(0, 7)) + list(range(11, 17)):
+# tile hints: 0 auto, 1..6 register-staged tiles, 11..16 LDS-DMA tiles, 21..26 persistent LDS-DMA tiles
+for _t in list(range(0, 7)) + list(range(11, 17)) + list(range(21, 27)):
     CASES[f"gemm_tile{_t:02d}_256x192x320"] = (lambda t=_t: _gemm_case(256, 192, 320, tile=t, seed=1))
     CASES[f"gemm_tile{_t:02d}_ragged_333x200x150_gelu_res"] = (
         lambda t=_t: _gemm_case(333, 200, 150, act="gelu", residual=True, tile=t, seed=2))
     CASES[f"gemm_tile{_t:02d}_600x320x520_relu_after_res_f32"] = (
         lambda t=_t: _gemm_case(600, 320, 520, act="relu", residual=True, act_after_res=True, out_f32=True, tile=t,
                                 seed=3))
+for _t in range(21, 27):
+    # more tiles than resident workgroups: every persistent workgroup walks several tiles (ragged M, N, K)
+    CASES[f"gemm_stream_multiround_tile{_t:02d}"] = (
+        lambda t=_t: _gemm_case(40000, 200, 520, act="gelu", residual=True, tile=t, seed=50 + t))
+    CASES[f"gemm_stream_k64_tile{_t:02d}"] = (lambda t=_t: _gemm_case(70000, 64, 256, act="relu", tile=t, seed=60 + t))
 CASES["gemm_vit_qkv_394x768x2304"] = lambda: _gemm_case(394, 768, 2304, seed=3)
 CASES["gemm_vit_fc2_394x3072x768_res"] = lambda: _gemm_case(394, 3072, 768, residual=True, seed=4)
 CASES["gemm_head_f32_8x768x1000"] = lambda: _gemm_case(8, 768, 1000, out_f32=True, seed=5)
@@ -203,10 +208,18 @@ CASES["conv3x3_s2_same_even"] = lambda: _conv_case(2, 20, 20, 16, 24, 3, 2, "sam
 CASES["conv3x3_scalar_cin6"] = lambda: _conv_case(2, 8, 8, 6, 10, 3, 1, 1, act="relu", seed=39)
 CASES["conv3x3_scalar_cin2_s2"] = lambda: _conv_case(3, 9, 9, 2, 4, 3, 2, 1, seed=40)
 CASES["conv1ch_8x8_patch"] = lambda: _conv_case(2, 32, 32, 1, 4, 8, 8, 0, bn=False, seed=41)
-for _t in (1, 2, 3, 4, 5, 6, 11, 12, 13, 14, 15, 16):
+for _t in (1, 2, 3, 4, 5, 6, 11, 12, 13, 14, 15, 16, 21, 22, 23, 24, 25, 26):
     CASES[f"conv3x3_tile{_t:02d}"] = (lambda t=_t: _conv_case(2, 16, 16, 64, 96, 3, 1, 1, act="relu", seed=42, tile=t))
     CASES[f"conv3x3_s2_res_tile{_t:02d}"] = (
         lambda t=_t: _conv_case(3, 15, 13, 40, 72, 3, 2, 1, act="relu", residual=True, seed=43, tile=t))
+
+
+for _t in (21, 24):
+    CASES[f"conv3x3_stream_multiround_tile{_t:02d}"] = (
+        lambda t=_t: _conv_case(32, 56, 56, 64, 64, 3, 1, 1, act="relu", residual=True, seed=70 + t, tile=t))
+CASES["conv3x3_cin128_tapstep"] = lambda: _conv_case(4, 14, 14, 128, 96, 3, 1, 1, act="relu", seed=75)
+CASES["conv3x3_s2_cin192_tapstep"] = lambda: _conv_case(3, 15, 15, 192, 64, 3, 2, 1, seed=76)
+CASES["conv1x1_s2_cin64_stream"] = lambda: _conv_case(2, 28, 28, 64, 128, 1, 2, 0, seed=77, tile=23)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -429,6 +442,8 @@ CASES["dwconv_k3_s1_same_c48"] = lambda: _dw_case(2, 19, 19, 48, 3, 1, "same", "
 CASES["dwconv_k3_s2_same_even"] = lambda: _dw_case(2, 20, 20, 144, 3, 2, "same", "swish", 91)
 CASES["dwconv_k5_s2_same_odd"] = lambda: _dw_case(2, 15, 15, 32, 5, 2, "same", "swish", 92)
 CASES["dwconv_k5_s2_same_even24"] = lambda: _dw_case(1, 24, 24, 16, 5, 2, "same", "swish", 93)
+CASES["dwconv_k5_s1_same_c960"] = lambda: _dw_case(3, 24, 24, 960, 5, 1, "same", "swish", 96)
+CASES["dwconv_k3_s2_same_95_c192"] = lambda: _dw_case(2, 95, 95, 192, 3, 2, "same", "swish", 97)
 CASES["dwconv_k7_p3_c96_linear"] = lambda: _dw_case(2, 14, 14, 96, 7, 1, 3, "", 94)
 CASES["dwconv_k3_p1_generic_c6"] = lambda: _dw_case(2, 8, 8, 6, 3, 1, 1, "relu", 95)
 

@@ -53,6 +53,13 @@ def test_micro_batch_equals_full_batch():
 
 
 def test_features_vit_mini():
-    r = mc.compare_model("vit_test_model", batch=2, features=True)
+    """Intermediate features.  embed_dim = 4 (the reference's own mini) puts a LayerNorm over 4
+    bf16-rounded values in front of every feature: one bf16 ulp of the residual stream moves a
+    normalised value by several percent, so that model gets the looser bar; the 128-wide mini
+    must meet the logits bar on every feature."""
+    r = mc.compare_model("vit_hd64_test_model", batch=2, features=True)
     bad = {k: v for k, v in r.items() if k.startswith("feat:") and v > mc.TOL_LOGITS}
+    assert not bad, bad
+    r = mc.compare_model("vit_test_model", batch=2, features=True)
+    bad = {k: v for k, v in r.items() if k.startswith("feat:") and v > 2 * mc.TOL_LOGITS}
     assert not bad, bad
