@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--micro-batch", type=int, default=int(os.environ.get("TFIMM_MICRO_BATCH", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every op eagerly instead of replaying a hipGraph")
     ap.add_argument("--extra", default=os.environ.get("TFIMM_BENCH_EXTRA", "vit_base_patch16_224"),
                     help="comma separated further workloads measured after the main one (reported under 'also')")
     return ap.parse_args()
@@ -62,7 +63,7 @@ def build_model(name):
     return model
 
 
-def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist):
+def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist, graph=True):
     """Returns dict(ms_per_step, kernel stats).  Timed region: barrier + sync, K steps, sync + barrier."""
     import torch
     cfg = model.cfg
@@ -82,15 +83,22 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
     logits = torch.empty(batch, out_t.C, dtype=torch.float32, device="cuda")
     gathered = torch.empty(world * batch, out_t.C, dtype=torch.float32, device="cuda") if world > 1 else None
 
+    use_graph = graph and mb == batch
+    captured = plans[batch].capture(x) if use_graph else None
+
     def step(events=None):
-        for s in range(0, batch, mb):
-            nb = min(mb, batch - s)
-            plan = plans[nb]
-            if events is None:
-                plan.run(x[s:s + nb])
-            else:
-                run_with_events(plan, x[s:s + nb], events)
-            logits[s:s + nb].copy_(plan.tensor_view(out_t).view(nb, out_t.C))
+        if captured is not None and events is None:
+            captured.replay()                              # one hipGraphLaunch: the whole layer program
+            logits.copy_(plans[batch].tensor_view(out_t).view(batch, out_t.C))
+        else:
+            for s in range(0, batch, mb):
+                nb = min(mb, batch - s)
+                plan = plans[nb]
+                if events is None:
+                    plan.run(x[s:s + nb])
+                else:
+                    run_with_events(plan, x[s:s + nb], events)
+                logits[s:s + nb].copy_(plan.tensor_view(out_t).view(nb, out_t.C))
         if world > 1:
             dist.all_gather_into_tensor(gathered, logits)
 
@@ -100,15 +108,25 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    events = [] if kernel_events else None
     t0 = time.perf_counter()
     for _ in range(steps):
-        step(events)
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # per-kernel durations: the same K steps again, launched eagerly with a HIP event pair (on the
+    # launch stream) around every GEMM-family launch -- events cannot be read back from inside a graph
+    events = [] if kernel_events else None
+    eager_dt = None
+    if events is not None:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            step(events)
+        torch.cuda.synchronize()
+        eager_dt = time.perf_counter() - t1
     stats = {}
     if events:
         for kind, flops, e0, e1 in events:
@@ -116,7 +134,8 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
             s_["ms"] += e0.elapsed_time(e1)
             s_["n"] += 1
             s_["flops"] += flops
-    return dict(seconds=dt, ms_per_step=dt / steps * 1e3, kernels=stats, logits=logits, x=x, prog=prog)
+    return dict(seconds=dt, ms_per_step=dt / steps * 1e3, kernels=stats, logits=logits, x=x, prog=prog,
+                graph=captured is not None, eager_events_ms_per_step=None if eager_dt is None else eager_dt / steps * 1e3)
 
 
 def run_with_events(plan, x_dev, events):
@@ -212,7 +231,8 @@ def main():
     wl = WORKLOADS[args.workload]
     batch = args.batch or wl["batch"]
     model = build_model(wl["model"])
-    r = measure(model, batch, args.micro_batch, args.steps, args.warmup, world, not args.no_kernel_events, dist)
+    r = measure(model, batch, args.micro_batch, args.steps, args.warmup, world, not args.no_kernel_events, dist,
+                graph=not args.no_graph)
 
     # max over ranks
     ms = r["ms_per_step"]
@@ -244,7 +264,9 @@ def main():
             roof = dict(bound=bound, achieved=round(achieved, 2), peak=peak, unit=punit,
                         frac=round(achieved / peak, 4), traffic=None, kernel="tfimm_gemm::gemm_kernel (all flavours)",
                         launches_per_step=launches_per_step, avg_launch_ms=round(avg_ms, 5),
-                        share_of_step=round(gk["ms"] / args.steps / ms, 3))
+                        share_of_step=round(gk["ms"] / args.steps / ms, 3),
+                        timing="HIP event pair around every launch, on the launch stream, over K eagerly launched "
+                               "steps run right after the timed region (which replays a hipGraph of the same launches)")
         cpu = None
         parity = None
         if world == 1 and not args.no_cpu_baseline:
@@ -262,6 +284,7 @@ def main():
             "config": {"workload": f"{wl['model']} @{model.cfg.input_size[0]} fwd", "per_gpu_batch": batch,
                        "global_batch": total_images, "micro_batch": args.micro_batch or batch,
                        "parallelism": f"dp{world}", "weights": "random-init (synthetic generator, seed 2021)",
+                       "launch": "hipGraph replay" if r["graph"] else "eager",
                        "gflops_per_image": round(flops_img / 1e9, 3)},
             "model_tflops": round(flops_img * total_images / ms / 1e9, 1),
             "roofline": roof, "cpu_baseline": cpu, "parity_vs_oracle": parity,
@@ -276,7 +299,8 @@ def main():
                 w2 = WORKLOADS[name]
                 m2 = build_model(w2["model"])
                 torch.cuda.empty_cache()
-                r2 = measure(m2, w2["batch"], 0, max(3, args.steps // 2), max(2, args.warmup // 2), 1, True, None)
+                r2 = measure(m2, w2["batch"], 0, max(3, args.steps // 2), max(2, args.warmup // 2), 1, True, None,
+                             graph=not args.no_graph)
                 gk = r2["kernels"].get("gemm")
                 fl = r2["prog"].flops_per_image()
                 also[name] = {"value": round(w2["batch"] / r2["ms_per_step"] * 1e3, 1), "unit": "images/sec",

@@ -1,0 +1,54 @@
+"""Data-parallel forward over the GPUs of one node: one process per GPU, weights replicated, the
+batch split in contiguous shards, and ONE exchange step -- an all-gather of the fp32 logits
+(RCCL over xGMI through ``torch.distributed``'s ``nccl`` backend).
+
+Images are independent at inference (BatchNorm uses moving statistics: every norm call in the
+reference passes ``training=training``, e.g. resnet.py:270,275,281), so there is no other
+collective on the path.  The helpers are backend-agnostic so the sharding / gather logic is
+covered by world-size-2 ``gloo`` tests on CPU (tests/test_distributed.py).
+"""
+from typing import Callable, Tuple
+
+
+def shard_bounds(batch: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of ``rank``; the first ``batch % world`` ranks get one extra image."""
+    q, r = divmod(batch, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def all_gather_rows(local, batch: int, dist=None):
+    """Gather per-rank row blocks ``local`` (shard_bounds order) into the full ``(batch, ...)`` tensor on
+    every rank.  Equal shards use one ``all_gather_into_tensor`` (a single ring pass over xGMI);
+    ragged shards are padded to the largest shard first."""
+    import torch
+    if dist is None:
+        import torch.distributed as dist
+    world = dist.get_world_size()
+    if world == 1:
+        return local
+    rank = dist.get_rank()
+    sizes = [shard_bounds(batch, world, r)[1] - shard_bounds(batch, world, r)[0] for r in range(world)]
+    assert local.shape[0] == sizes[rank], (local.shape, sizes, rank)
+    mx = max(sizes)
+    if local.shape[0] != mx:
+        pad = torch.zeros((mx - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], dim=0)
+    out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    if all(s == mx for s in sizes):
+        return out
+    return torch.cat([out[r * mx:r * mx + sizes[r]] for r in range(world)], dim=0)
+
+
+def dp_forward(forward: Callable, x, dist=None):
+    """``forward`` maps a local image batch to local logits (a torch tensor).  ``x`` is the GLOBAL
+    batch (every rank holds it, or at least its own shard's rows are valid): each rank runs its
+    shard and all ranks return the full ``(B, nb_classes)`` logits."""
+    if dist is None:
+        import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return forward(x)
+    lo, hi = shard_bounds(x.shape[0], world, dist.get_rank())
+    return all_gather_rows(forward(x[lo:hi]), x.shape[0], dist)

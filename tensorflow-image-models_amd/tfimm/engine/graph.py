@@ -652,6 +652,9 @@ class Plan:
             tuned += 1
         return tuned
 
+    def capture(self, x_dev) -> "CapturedPlan":
+        return CapturedPlan(self, x_dev)
+
     def check_marshalling(self):
         """Convert every recorded argument through the ctypes prototypes (no launch): catches
         arity / type slips in the call list without a GPU.  Returns the number of calls."""
@@ -692,6 +695,28 @@ class Plan:
                 rc = fn(*args, st)
             if rc != 0:
                 ffi.check(rc, f"op {i} ({getattr(fn, '__name__', fn)})")
+
+
+class CapturedPlan:
+    """A plan recorded into a HIP graph (through torch.cuda.CUDAGraph, which drives
+    hipStreamBeginCapture on the stream the C ABI launches on): one ``hipGraphLaunch`` per forward
+    instead of ~100 ctypes calls + kernel launches.  The input pointer is baked into the graph, so
+    callers either keep writing into ``static_input`` or replay on the tensor that was captured."""
+
+    def __init__(self, plan: "Plan", x_dev):
+        import torch
+        self.plan = plan
+        self.static_input = x_dev
+        # every lazy host-side initialisation (function attributes, occupancy queries) must have
+        # happened before capture: run the plan once eagerly
+        plan.run(x_dev)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            plan.run(x_dev)
+
+    def replay(self):
+        self.graph.replay()
 
 
 def _hip_memset_async(ptr: int, nbytes: int, stream_ptr: int) -> int:

@@ -1,0 +1,47 @@
+"""Freeze known-answer vectors of the forward path (SURVEY.md §8c "golden vectors to create and
+freeze": the reference ships none and cannot run here -- TensorFlow is not installable).
+
+For each model: weights from the deterministic non-degenerate generator (seed 2021), input
+``default_rng(2021).random((B,H,W,C))`` + the model's preprocessing (the recipe of the reference's
+tests/test_timm.py:56-59), fp32 CPU-oracle logits and per-block features.  Written to
+tests/golden/forward_golden.npz;  regenerate with  ``python tests/golden/make_golden.py``.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.join(ROOT, "tensorflow-image-models_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+MODELS = [("vit_test_model", 2), ("deit_test_model", 2), ("vit_hd64_test_model", 2), ("resnet_test_model_1", 2),
+          ("resnet_test_model_2", 2), ("resnet50_mini_test_model", 2), ("seresnet_test_model", 2),
+          ("swin_test_model", 2), ("swin_shift_test_model", 2), ("efficientnet_test_model", 2),
+          ("efficientnet_same_test_model", 2), ("vit_tiny_patch16_224", 1)]
+
+
+def main():
+    os.environ.setdefault("TFIMM_ALLOW_NO_GPU", "1")
+    import model_checks as mc
+    import oracle
+    import test_architectures  # noqa: F401
+    import tfimm
+    from tfimm.utils.init import synthetic_weights
+    out = {}
+    for name, batch in MODELS:
+        model = tfimm.create_model(name)
+        w = synthetic_weights(model, 2021)
+        x = mc.make_input(model.cfg, batch)
+        logits, feats = oracle.forward(model.cfg, w, x, return_features=True)
+        out[f"{name}/logits"] = np.asarray(logits, np.float32)
+        if batch > 1:   # features of the minis only (full-size feature maps are large)
+            for k, v in feats.items():
+                out[f"{name}/feat/{k}"] = np.asarray(v, np.float32)
+        print(name, np.asarray(logits).shape, float(np.abs(logits).max()))
+    np.savez_compressed(os.path.join(HERE, "forward_golden.npz"), **out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,82 @@
+"""World-size-2 gloo tests (CPU) of the data-parallel path: shard bounds, the logits all-gather
+(equal and ragged shards) and dp_forward == single-process forward.  The forward used here is the
+fp32 CPU oracle -- the collective logic under test is the code bench.py / users run over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, batch, q):
+    for p in (ROOT, os.path.join(ROOT, "tensorflow-image-models_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        import test_architectures  # noqa: F401
+        import tfimm
+        from tfimm.engine import dp
+        from tfimm.utils.init import synthetic_weights
+        import model_checks as mc
+        model = tfimm.create_model("resnet_test_model_2")
+        w = synthetic_weights(model, 2021)
+        x = torch.from_numpy(mc.make_input(model.cfg, batch))
+
+        def forward(xs):
+            return torch.from_numpy(np.asarray(oracle.forward(model.cfg, w, xs.numpy()), dtype=np.float32))
+
+        full = forward(x)
+        got = dp.dp_forward(forward, x)
+        lo, hi = dp.shard_bounds(batch, world, rank)
+        q.put((rank, lo, hi, float((got - full).abs().max()), tuple(got.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch", [4, 5])
+def test_dp_forward_matches_single_process(batch):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort()
+    assert res[0][1] == 0 and res[-1][2] == batch and res[0][2] == res[1][1]   # contiguous cover
+    for rank, lo, hi, err, shape in res:
+        assert shape == (batch, 12), shape
+        assert err < 1e-5, (rank, err)   # every rank holds the full, identical logits
+
+
+def test_shard_bounds():
+    sys.path.insert(0, os.path.join(ROOT, "tensorflow-image-models_amd"))
+    from tfimm.engine.dp import shard_bounds
+    for batch in (1, 7, 8, 2048):
+        for world in (1, 2, 3, 8):
+            b = [shard_bounds(batch, world, r) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == batch
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,50 @@
+"""Known-answer tests against tests/golden/forward_golden.npz (made by tests/golden/make_golden.py).
+
+CPU: the oracle must keep reproducing the frozen vectors (pins the restatement and the weight
+generator against silent drift).  GPU: the HIP engine against the same frozen logits."""
+import os
+
+import numpy as np
+import pytest
+
+import model_checks as mc
+import oracle
+import test_architectures  # noqa: F401
+import tfimm
+from tfimm.utils.init import synthetic_weights
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "forward_golden.npz"))
+MODELS = sorted({k.split("/")[0] for k in GOLD.files})
+
+
+def _setup(name):
+    model = tfimm.create_model(name)
+    w = synthetic_weights(model, 2021)
+    batch = GOLD[f"{name}/logits"].shape[0]
+    return model, w, mc.make_input(model.cfg, batch)
+
+
+@pytest.mark.parametrize("name", [m for m in MODELS if m != "vit_tiny_patch16_224"])
+def test_oracle_reproduces_golden(name):
+    model, w, x = _setup(name)
+    logits, feats = oracle.forward(model.cfg, w, x, return_features=True)
+    assert mc.rel_err(logits, GOLD[f"{name}/logits"]) <= 1e-4
+    for k, v in feats.items():
+        assert mc.rel_err(v, GOLD[f"{name}/feat/{k}"]) <= 1e-4, k
+
+
+def test_oracle_reproduces_golden_vit_tiny_b1():
+    """BASELINE.json configs[0]: vit_tiny_patch16_224, batch 1, CPU forward."""
+    model, w, x = _setup("vit_tiny_patch16_224")
+    assert mc.rel_err(oracle.forward(model.cfg, w, x), GOLD["vit_tiny_patch16_224/logits"]) <= 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", MODELS)
+def test_engine_matches_golden(name):
+    model, w, x = _setup(name)
+    model.set_weights(w)
+    ref = GOLD[f"{name}/logits"]
+    got = model(x).numpy().reshape(ref.shape)
+    assert mc.rel_err(got, ref) <= mc.TOL_LOGITS
+    assert (got.argmax(-1) == ref.argmax(-1)).all()
