@@ -156,7 +156,7 @@ def run_with_events(plan, x_dev, events):
     gemm_ops = plan.__dict__.setdefault("_gemm_ops", [op for op in plan.prog.ops if op.kind == "gemm"])
     for i, (fn, args) in enumerate(plan.calls):
         if i == idx:
-            rc = fn(x_dev.data_ptr(), in_dtype, out, npix, c_in, c_out, st)
+            rc = fn(x_dev.data_ptr(), in_dtype, *plan._input_call[1], st)
         elif fn == "memset":
             rc = _hip_memset_async(args[0], args[1], stream_ptr)
         elif fn is gemm_fn:

@@ -107,6 +107,10 @@ typedef struct tfimm_gemm_desc {
   int32_t B, H, W, Cin, KH, KW, stride, pad_t, pad_l, OH, OW;
   int32_t rows_per_image;
   int32_t tile_hint;      /* 0 = auto; otherwise index into the kernel table (benchmarks) */
+  int32_t stride_w;       /* TFIMM_A_CONV only: horizontal stride if it differs from `stride` (0 = same).
+                             Lets a stride-2 RGB stem / patch embedding run on the pixel-PAIR view of a
+                             zero-padded 4-channel image ([B][Hp][Wp/2][8], see tfimm_hip_cast_input_pad):
+                             vertical stride s, horizontal stride s/2, kernel width ceil(KW/2). */
 } tfimm_gemm_desc;
 
 TFIMM_API int tfimm_hip_gemm(const tfimm_gemm_desc* d, void* stream);
@@ -118,6 +122,14 @@ TFIMM_API int tfimm_hip_gemm(const tfimm_gemm_desc* d, void* stream);
  * ------------------------------------------------------------------------------------- */
 TFIMM_API int tfimm_hip_cast_input(const void* in, int in_dtype, void* out, int64_t n_pixels,
                          int c_in, int c_out, void* stream);
+
+/* tfimm_hip_cast_input_pad: as tfimm_hip_cast_input for c_in <= 4 -> 4 stored channels, but writes the
+ * image into the interior of a zero border: out[B][H + pad_t + pad_b][W + pad_l + pad_r][4].  This is
+ * the ZeroPadding2D / "same" padding in front of a stem convolution (resnet.py:505, layers/conv.py:61)
+ * done once while the input is converted, so the convolution itself needs no bounds checks and its
+ * operand tiles can be fetched by LDS-DMA. */
+TFIMM_API int tfimm_hip_cast_input_pad(const void* in, int in_dtype, void* out, int B, int H, int W, int c_in,
+                             int pad_t, int pad_b, int pad_l, int pad_r, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * tfimm_hip_layernorm: y[r][:] = (x[r][:] - mean) * rsqrt(var + eps) * gamma + beta,

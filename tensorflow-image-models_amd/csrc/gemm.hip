@@ -171,6 +171,7 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
   g.B = d.B; g.H = d.H; g.W = d.W; g.Cin = d.Cin; g.KH = d.KH; g.KW = d.KW;
   g.KWp = (d.KW + 1) & ~1;
   g.stride = d.stride; g.pad_t = d.pad_t; g.pad_l = d.pad_l; g.OH = d.OH; g.OW = d.OW;
+  g.stride_w = d.stride_w > 0 ? d.stride_w : d.stride;
   g.rows_per_image = d.rows_per_image;
 
   int kmode;
@@ -212,7 +213,7 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
     const int64_t a_bytes = (d.mode == TFIMM_A_DENSE) ? ((int64_t)(d.M - 1) * d.lda + d.K) * 2
                                                        : (int64_t)d.B * d.H * d.W * d.Cin * 2;
     const int64_t w_bytes = (int64_t)d.N * d.ldw * 2;
-    const bool hinted_other = d.tile_hint > 0 && d.tile_hint <= 20;
+    const bool hinted_other = d.tile_hint > 0 && d.tile_hint <= 20 && g.stride_w == g.stride;
     // extents of the output / residual buffers as the epilogue addresses them (row remap included)
     const int64_t out_rows = d.remap_in > 0 ? ((int64_t)(d.M - 1) / d.remap_in) * d.remap_out + d.remap_in + d.remap_off : d.M;
     const int64_t out_bytes = ((out_rows - 1) * d.ldc + d.N) * (d.out_f32 ? 4 : 2);
@@ -255,6 +256,11 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       if (ntiles > 0x7fffffffLL) TFIMM_FAIL(TFIMM_EINVAL, "gemm: grid too large");
       ga.n_tiles = (int)ntiles;
       ga.cin64 = (kmode == K_CONV && (d.Cin % 64) == 0) ? 1 : 0;
+      ga.cin_magic = ga.kw_magic = 0;
+      if (kmode == K_CONV && d.K < 65536) {
+        if (d.Cin > 1) ga.cin_magic = (unsigned)(0x100000000ULL / (unsigned)d.Cin) + 1u;
+        if (d.KW > 1) ga.kw_magic = (unsigned)(0x100000000ULL / (unsigned)d.KW) + 1u;
+      }
       int64_t grid = (int64_t)num_cu() * occ_f[ti];
       grid = (grid + 7) / 8 * 8;
       const int64_t need = (ntiles + 7) / 8 * 8;
@@ -263,6 +269,9 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       return 0;
     }
   }
+
+  if (d.mode != TFIMM_A_DENSE && g.stride_w != g.stride)
+    TFIMM_FAIL(TFIMM_EUNSUP, "gemm: stride_w != stride needs the persistent LDS-DMA family (Cin %% 8 == 0, 16-byte aligned input)");
 
   // ---- LDS-DMA family: aligned dense rows or Cin % 8 == 0 gathers, weights padded to 64 in k,
   //      tensors addressable with a 31-bit byte offset

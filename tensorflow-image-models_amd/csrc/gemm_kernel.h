@@ -52,6 +52,7 @@ struct GemmArgs {
   int out_f32, act, act_after_res, res_mod;
   int remap_in, remap_out, remap_off;
   int B, H, W, Cin, KH, KW, KWp, stride, pad_t, pad_l, OH, OW;
+  int stride_w;   // horizontal stride (== stride unless the pixel-pair view of an RGB stem is used)
   int rows_per_image;
   int res_vec;    // residual rows can be read as aligned 8-byte quads
   int out_vec;    // output rows can be written as aligned quads

@@ -41,6 +41,7 @@ struct GemmStreamArgs {
   unsigned out_bytes, res_bytes;   // extents of the output / residual buffers (descriptor bounds)
   int n_tiles;       // tiles_m * tiles_n
   int cin64;         // K_CONV: Cin % 64 == 0 (scalar tap stepping)
+  unsigned cin_magic, kw_magic;   // K_CONV otherwise: floor(2^32 / d) + 1 for d = Cin, KW (0: K >= 65536, divide)
 };
 
 typedef void (*gemm_stream_fn)(const GemmStreamArgs);
@@ -192,7 +193,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
         const int rem = mm - b * ohw;
         const int oy = rem / p.OW, ox = rem - oy * p.OW;
         a_iy0[j] = ok ? oy * p.stride - p.pad_t : -(1 << 28);
-        a_ix0[j] = ox * p.stride - p.pad_l;
+        a_ix0[j] = ox * p.stride_w - p.pad_l;
         a_pix[j] = b * p.H * p.W;
         a_off[j] = 0;
       }
@@ -207,52 +208,65 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
     s_ky = s_kx = s_ci0 = 0;
   };
 
-  auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+  // One 1-KiB DMA piece of the step being issued: pieces [0, B_INSTR) are this wave's weight rows,
+  // [B_INSTR, B_INSTR + A_INSTR) its activation rows.  (Measured: spreading the pieces over the
+  // k-slices of the previous step instead of issuing them in one block behind the barrier, and
+  // s_setprio around the MFMA groups, are both neutral in this one-barrier-per-k-tile structure.
+  // What the DMA costs is LDS time: with the DMA removed the same loop runs 622k instead of 867k
+  // cycles per wave on M=100864 K=3072 N=768, i.e. ~1100 cycles per k-step of fragment-read stall
+  // while 64 KiB of DMA writes share the LDS with 192 KiB of ds_read_b128 traffic.)
+  constexpr int N_PIECES = A_INSTR + B_INSTR;
+  auto issue_piece = [&](int piece, int kt, int stage) __attribute__((always_inline)) {
     char* sa = smem + stage * STAGE;
     char* sb = sa + A_BYTES;
     const int kbytes = kt * 128;
-    // B (weights): rows are zero padded to a multiple of 64 -> always in range in k
-#pragma unroll
-    for (int j = 0; j < B_INSTR; ++j) {
+    if (piece < B_INSTR) {
+      // B (weights): rows are zero padded to a multiple of 64 -> always in range in k
+      const int j = piece;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(sb + (wave * B_INSTR + j) * 1024), 16,
                                                (int)b_off[j], kbytes, 0, 0);
-    }
-    if (KMODE == K_DENSE) {
-#pragma unroll
-      for (int j = 0; j < A_INSTR; ++j) {
-        const bool kok = (kt * BK + a_chunk(j) * 8) < p.K;
-        const unsigned off = kok ? a_off[j] : kOobOffset;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sa + (wave * A_INSTR + j) * 1024), 16,
-                                                 (int)off, kbytes, 0, 0);
-      }
+    } else if (KMODE == K_DENSE) {
+      const int j = piece - B_INSTR;
+      const bool kok = (kt * BK + a_chunk(j) * 8) < p.K;
+      const unsigned off = kok ? a_off[j] : kOobOffset;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sa + (wave * A_INSTR + j) * 1024), 16,
+                                               (int)off, kbytes, 0, 0);
     } else {
-#pragma unroll
-      for (int j = 0; j < A_INSTR; ++j) {
-        int ky, kx, ci;
-        bool kok = true;
-        if (pa.cin64) {   // whole k-tile inside tap (s_ky, s_kx), channels s_ci0 .. s_ci0 + 63
-          ky = s_ky; kx = s_kx; ci = s_ci0 + a_chunk(j) * 8;
-        } else {
-          const int kg = kt * BK + a_chunk(j) * 8;
-          const int tap = kg / p.Cin;
-          ci = kg - tap * p.Cin;
-          ky = tap / p.KW; kx = tap - ky * p.KW;
-          kok = kg < p.K;
-        }
-        const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
-        const bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const unsigned off = ok ? (unsigned)((((size_t)(a_pix[j] + iy * p.W + ix)) * p.Cin + ci) * 2) : kOobOffset;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sa + (wave * A_INSTR + j) * 1024), 16,
-                                                 (int)off, 0, 0, 0);
+      const int j = piece - B_INSTR;
+      int ky, kx, ci;
+      bool kok = true;
+      if (pa.cin64) {   // whole k-tile inside tap (s_ky, s_kx), channels s_ci0 .. s_ci0 + 63
+        ky = s_ky; kx = s_kx; ci = s_ci0 + a_chunk(j) * 8;
+      } else {
+        // k -> (ky, kx, ci): exact multiply-high division (k < 65536), one per DMA piece per k-tile
+        const int kg = kt * BK + a_chunk(j) * 8;
+        const int tap = pa.cin_magic ? (int)__umulhi((unsigned)kg, pa.cin_magic) : kg / p.Cin;
+        ci = kg - tap * p.Cin;
+        ky = pa.kw_magic ? (int)__umulhi((unsigned)tap, pa.kw_magic) : tap / p.KW;
+        kx = tap - ky * p.KW;
+        kok = kg < p.K;
       }
-      if (pa.cin64) {
-        s_ci0 += BK;
-        if (s_ci0 >= p.Cin) {
-          s_ci0 = 0;
-          if (++s_kx == p.KW) { s_kx = 0; ++s_ky; }
-        }
+      const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+      const bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const unsigned off = ok ? (unsigned)((((size_t)(a_pix[j] + iy * p.W + ix)) * p.Cin + ci) * 2) : kOobOffset;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sa + (wave * A_INSTR + j) * 1024), 16,
+                                               (int)off, 0, 0, 0);
+    }
+  };
+  // after the last piece of a step: advance the scalar tap state of the NHWC gather
+  auto issue_done = [&]() __attribute__((always_inline)) {
+    if (KMODE == K_CONV && pa.cin64) {
+      s_ci0 += BK;
+      if (s_ci0 >= p.Cin) {
+        s_ci0 = 0;
+        if (++s_kx == p.KW) { s_kx = 0; ++s_ky; }
       }
     }
+  };
+  auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < N_PIECES; ++q) issue_piece(q, kt, stage);
+    issue_done();
   };
 
   const int frow = lane & 31;

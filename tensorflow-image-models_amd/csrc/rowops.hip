@@ -73,6 +73,29 @@ __global__ void cast_rgb4_kernel(const void* in, uint2* out, int64_t n_pixels) {
   }
 }
 
+// image -> zero-bordered 4-channel bf16 image (one thread per OUTPUT pixel)
+template <bool IN_BF16>
+__global__ void cast_pad4_kernel(const void* in, uint2* out, int B, int H, int W, int c_in, int pad_t, int pad_l,
+                                 int HP, int WP) {
+  const int64_t total = (int64_t)B * HP * WP;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+    const int xp = (int)(id % WP);
+    const int64_t t = id / WP;
+    const int yp = (int)(t % HP);
+    const int b = (int)(t / HP);
+    const int y = yp - pad_t, x = xp - pad_l;
+    uint32_t c[4] = {0u, 0u, 0u, 0u};
+    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+      const int64_t px = ((int64_t)b * H + y) * W + x;
+      for (int e = 0; e < c_in; ++e) {
+        if (IN_BF16) c[e] = reinterpret_cast<const bf16_t*>(in)[px * c_in + e];
+        else c[e] = f2bf(reinterpret_cast<const float*>(in)[px * c_in + e]);
+      }
+    }
+    out[id] = make_uint2(c[0] | (c[1] << 16), c[2] | (c[3] << 16));
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // layernorm: one wave per row, row cached in registers (vector path) or re-read (generic)
 // ---------------------------------------------------------------------------------------
@@ -540,6 +563,19 @@ extern "C" int tfimm_hip_cast_input(const void* in, int in_dtype, void* out, int
     if (in_dtype) TFIMM_LAUNCH(cast_input_kernel<true>, dim3(grid), dim3(256), 0, st, in, (bf16_t*)out, n_pixels, c_in, c_out);
     else TFIMM_LAUNCH(cast_input_kernel<false>, dim3(grid), dim3(256), 0, st, in, (bf16_t*)out, n_pixels, c_in, c_out);
   }
+  return 0;
+}
+
+extern "C" int tfimm_hip_cast_input_pad(const void* in, int in_dtype, void* out, int B, int H, int W, int c_in,
+                                        int pad_t, int pad_b, int pad_l, int pad_r, void* stream) {
+  if (!in || !out || B <= 0 || H <= 0 || W <= 0 || c_in <= 0 || c_in > 4 || pad_t < 0 || pad_b < 0 || pad_l < 0 ||
+      pad_r < 0 || (in_dtype != 0 && in_dtype != 1) || ((uintptr_t)out & 7))
+    TFIMM_FAIL(TFIMM_EINVAL, "cast_input_pad: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int HP = H + pad_t + pad_b, WP = W + pad_l + pad_r;
+  const unsigned grid = grid_for((int64_t)B * HP * WP, 256);
+  if (in_dtype) TFIMM_LAUNCH(cast_pad4_kernel<true>, dim3(grid), dim3(256), 0, st, in, (uint2*)out, B, H, W, c_in, pad_t, pad_l, HP, WP);
+  else TFIMM_LAUNCH(cast_pad4_kernel<false>, dim3(grid), dim3(256), 0, st, in, (uint2*)out, B, H, W, c_in, pad_t, pad_l, HP, WP);
   return 0;
 }
 

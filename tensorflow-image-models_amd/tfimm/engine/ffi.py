@@ -34,7 +34,7 @@ class GemmDesc(C.Structure):
         ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32),
         ("pad_t", C.c_int32), ("pad_l", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32),
-        ("rows_per_image", C.c_int32), ("tile_hint", C.c_int32),
+        ("rows_per_image", C.c_int32), ("tile_hint", C.c_int32), ("stride_w", C.c_int32),
     ]
 
 
@@ -55,6 +55,7 @@ SYMBOLS = {
     "tfimm_hip_device_info": (_i, [_i, C.c_char_p, _i]),
     "tfimm_hip_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "tfimm_hip_cast_input": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp]),
+    "tfimm_hip_cast_input_pad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tfimm_hip_layernorm": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i64, _i64, _f, _vp]),
     "tfimm_hip_attention": (_i, [C.POINTER(AttnDesc), _vp]),
     "tfimm_hip_maxpool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -201,7 +201,9 @@ class Builder:
         p.input = raw
         p.input_shape = (H, W, cin)
         x = p.new_tensor(H * W, cpad, H, W, name="input_bf16")
-        p.add("cast_input", [raw], x, c_in=cin, c_out=cpad, cite="Keras input autocast")
+        self._cast_op = p.add("cast_input", [raw], x, c_in=cin, c_out=cpad, H=H, W=W, pad=(0, 0, 0, 0),
+                              cite="Keras input autocast")
+        self._cast_out = x.id
         return x
 
     # -- convolution / dense -----------------------------------------------------------------
@@ -247,7 +249,23 @@ class Builder:
         attrs = dict(M=M, N=cout, K_true=kh * kw * cin, act=act, act_after_res=act_after_res,
                      out_f32=0, res_mod=res_mod, remap=remap)
         pointwise = (kh == 1 and kw == 1 and stride == 1 and pt == 0 and pl == 0 and x.C == cin)
-        if pointwise:
+        # RGB stem / patch embedding with an even stride: the zero padding is written once by the input
+        # cast (tfimm_hip_cast_input_pad) and the conv runs on the pixel-PAIR view [Hp][Wp/2][8] of the
+        # padded 4-channel image -- no bounds checks, Cin % 8 == 0, so the operand tiles go by LDS-DMA.
+        pair_view = (x.C == 4 and getattr(self, "_cast_out", None) == x.id and stride % 2 == 0 and a_scale is None
+                     and self._cast_op.attrs["pad"] == (0, 0, 0, 0) and not self._cast_op.attrs.get("used"))
+        if pair_view:
+            kwp = (kw + 1) // 2 * 2
+            wp = max(x.W + pl, (OW - 1) * stride + kwp)
+            wp += wp & 1
+            hp = max(x.H + pt, (OH - 1) * stride + kh)
+            self._cast_op.attrs.update(pad=(pt, hp - x.H - pt, pl, wp - x.W - pl), used=True)
+            xt = p.tensors[x.id]
+            xt.rows, xt.H, xt.W = hp * wp, hp, wp
+            wt, bvec, kk, _ = pack.pack_conv(k, scale, shift, 4)   # K order (ky, kx < kwp, c < 4) == (ky, pair, 8)
+            attrs.update(mode=1, K=kk, H=hp, W=wp // 2, Cin=8, KH=kh, KW=kwp // 2, stride=stride, stride_w=stride // 2,
+                         pad_t=0, pad_l=0, OH=OH, OW=OW)
+        elif pointwise:
             wt, bvec = pack.pack_dense(k.reshape(cin, cout) * (1.0 if scale is None else scale.reshape(1, cout)), shift)
             attrs.update(mode=0, K=cin, lda=x.C, a_rows_per_image=x.rows)
         else:
@@ -487,6 +505,7 @@ class Plan:
         self._keepalive = []
         self.calls: List[Tuple[Callable, tuple]] = []
         self._input_patch = None
+        self._input_call = None
         self._gemm_descs = []
         self._build()
         if device != "cpu" and tune.autotune_enabled():
@@ -521,7 +540,12 @@ class Plan:
                 out = self.tptr(op.output)
                 H, W, cin = prog.input_shape
                 self._input_patch = (len(self.calls), out, B * H * W, a["c_in"], a["c_out"])
-                self.calls.append((lib.tfimm_hip_cast_input, None))  # args patched per call
+                if a["pad"] != (0, 0, 0, 0):
+                    pt_, pb_, pl_, pr_ = a["pad"]
+                    self._input_call = (lib.tfimm_hip_cast_input_pad, (out, B, H, W, a["c_in"], pt_, pb_, pl_, pr_))
+                else:
+                    self._input_call = (lib.tfimm_hip_cast_input, (out, B * H * W, a["c_in"], a["c_out"]))
+                self.calls.append((self._input_call[0], None))  # input pointer / dtype patched per call
             elif k == "gemm":
                 d = ffi.GemmDesc()
                 a_ptr = self.tptr(op.inputs[0])
@@ -537,6 +561,7 @@ class Plan:
                     d.B, d.H, d.W, d.Cin = B, a["H"], a["W"], a["Cin"]
                     d.KH, d.KW, d.stride = a["KH"], a["KW"], a["stride"]
                     d.pad_t, d.pad_l, d.OH, d.OW = a["pad_t"], a["pad_l"], a["OH"], a["OW"]
+                    d.stride_w = a.get("stride_w", 0)
                 d.a = a_ptr
                 d.wt = self.cptr(op.consts["wt"])
                 d.bias = self.cptr(op.consts.get("bias"))
@@ -664,8 +689,7 @@ class Plan:
                 assert len(args) == 2
                 continue
             if args is None:  # cast_input: patched per call
-                _, out, npix, c_in, c_out = self._input_patch
-                args = (0, 0, out, npix, c_in, c_out)
+                args = (0, 0) + tuple(self._input_call[1])
             protos = fn.argtypes
             if len(args) + 1 != len(protos):
                 raise TypeError(f"call {i} ({fn.__name__}): {len(args) + 1} args for {len(protos)} parameters")
@@ -687,7 +711,7 @@ class Plan:
         in_dtype = 1 if x_dev.dtype == torch.bfloat16 else 0
         for i, (fn, args) in enumerate(self.calls):
             if i == idx:
-                rc = fn(x_dev.data_ptr(), in_dtype, out, npix, c_in, c_out, st)
+                rc = fn(x_dev.data_ptr(), in_dtype, *self._input_call[1], st)
             elif fn == "memset":
                 ffi.check(_hip_memset_async(args[0], args[1], stream_ptr), "hipMemsetAsync")
                 continue

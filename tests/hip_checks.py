@@ -157,7 +157,7 @@ def _():
 # ---------------------------------------------------------------------------------------------
 # convolutions through the GEMM gather modes
 # ---------------------------------------------------------------------------------------------
-def _conv_case(B, H, W, Cin, Cout, k, stride, padding, *, act="", bn=True, residual=False, seed=0, tile=0):
+def _conv_case(B, H, W, Cin, Cout, k, stride, padding, *, act="", bn=True, residual=False, seed=0, tile=0, pair=False):
     import hip_ops as Hh
     r = _rng(seed)
     x = _bf(r.standard_normal((B, H, W, Cin)))
@@ -186,9 +186,20 @@ def _conv_case(B, H, W, Cin, Cout, k, stride, padding, *, act="", bn=True, resid
     else:
         y = O.activation(y, act)
     xd = Hh.dev_bf16(x)
-    if cin_stored != Cin:
-        xd = Hh.cast_input(xd, cin_stored)
-    conv = dict(mode=mode, B=B, H=H, W=W, Cin=cin_stored, KH=k, KW=k, stride=stride, pad_t=pt, pad_l=pl, OH=OH, OW=OW)
+    if pair:
+        # RGB stem on the pixel-pair view of the zero-bordered image (what graph.Builder.conv emits)
+        assert cin_stored == 4 and stride % 2 == 0
+        kwp = (k + 1) // 2 * 2
+        wp = max(W + pl, (OW - 1) * stride + kwp)
+        wp += wp & 1
+        hp = max(H + pt, (OH - 1) * stride + k)
+        xd = Hh.cast_input_pad(xd, (pt, hp - H - pt, pl, wp - W - pl))
+        conv = dict(mode=1, B=B, H=hp, W=wp // 2, Cin=8, KH=k, KW=kwp // 2, stride=stride, stride_w=stride // 2,
+                    pad_t=0, pad_l=0, OH=OH, OW=OW)
+    else:
+        if cin_stored != Cin:
+            xd = Hh.cast_input(xd, cin_stored)
+        conv = dict(mode=mode, B=B, H=H, W=W, Cin=cin_stored, KH=k, KW=k, stride=stride, pad_t=pt, pad_l=pl, OH=OH, OW=OW)
     got = Hh.gemm(xd, Hh.dev_bits(wt), Cout, K, bias=None if bias is None else Hh.dev_f32(bias),
                   residual=None if res is None else Hh.dev_bf16(res.reshape(-1, Cout)), act=act,
                   act_after_res=residual, conv=conv, tile_hint=tile)
@@ -214,6 +225,13 @@ for _t in (1, 2, 3, 4, 5, 6, 11, 12, 13, 14, 15, 16, 21, 22, 23, 24, 25, 26):
         lambda t=_t: _conv_case(3, 15, 13, 40, 72, 3, 2, 1, act="relu", residual=True, seed=43, tile=t))
 
 
+CASES["pair_conv7x7_s2_p3_rgb_stem"] = lambda: _conv_case(2, 64, 64, 3, 64, 7, 2, 3, act="relu", seed=134, pair=True)
+CASES["pair_conv7x7_s2_p3_rgb_stem_big"] = lambda: _conv_case(3, 224, 224, 3, 64, 7, 2, 3, act="relu", seed=139, pair=True)
+CASES["pair_conv16x16_s16_rgb_patch"] = lambda: _conv_case(2, 64, 64, 3, 96, 16, 16, 0, bn=False, seed=135, pair=True)
+CASES["pair_conv4x4_s4_rgb_patch"] = lambda: _conv_case(2, 32, 32, 3, 128, 4, 4, 0, seed=136, pair=True)
+CASES["pair_conv3x3_s2_same_rgb_odd"] = lambda: _conv_case(2, 33, 33, 3, 48, 3, 2, "same", act="swish", seed=137, pair=True)
+CASES["pair_conv3x3_s2_same_rgb_380"] = lambda: _conv_case(1, 380, 380, 3, 48, 3, 2, "same", act="swish", seed=140, pair=True)
+CASES["pair_conv1ch_8x8_patch"] = lambda: _conv_case(2, 32, 32, 1, 8, 8, 8, 0, bn=False, seed=138, pair=True)
 for _t in (21, 24):
     CASES[f"conv3x3_stream_multiround_tile{_t:02d}"] = (
         lambda t=_t: _conv_case(32, 56, 56, 64, 64, 3, 1, 1, act="relu", residual=True, seed=70 + t, tile=t))

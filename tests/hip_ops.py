@@ -58,6 +58,7 @@ def gemm(a, wt, N, K, *, M=None, bias=None, residual=None, out=None, act="", act
         d.B, d.H, d.W, d.Cin = conv["B"], conv["H"], conv["W"], conv["Cin"]
         d.KH, d.KW, d.stride = conv["KH"], conv["KW"], conv["stride"]
         d.pad_t, d.pad_l, d.OH, d.OW = conv["pad_t"], conv["pad_l"], conv["OH"], conv["OW"]
+        d.stride_w = conv.get("stride_w", 0)
         M = conv["B"] * conv["OH"] * conv["OW"]
     d.M, d.N, d.K = M, N, K
     d.ldw = wt.shape[1]
@@ -107,6 +108,16 @@ def cast_input(x, c_out):
     out = torch.empty(B, H, W, c_out, dtype=torch.bfloat16, device=DEV)
     ffi.check(lib.tfimm_hip_cast_input(ptr(x), 1 if x.dtype == torch.bfloat16 else 0, ptr(out), B * H * W, Cin,
                                        c_out, stream()), "cast_input")
+    return out
+
+
+def cast_input_pad(x, pad):
+    """pad = (top, bottom, left, right); returns the zero-bordered 4-channel bf16 image."""
+    B, H, W, Cin = x.shape
+    pt, pb, pl, pr = pad
+    out = torch.empty(B, H + pt + pb, W + pl + pr, 4, dtype=torch.bfloat16, device=DEV)
+    ffi.check(lib.tfimm_hip_cast_input_pad(ptr(x), 1 if x.dtype == torch.bfloat16 else 0, ptr(out), B, H, W, Cin,
+                                           pt, pb, pl, pr, stream()), "cast_input_pad")
     return out
 
 

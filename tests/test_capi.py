@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 from tfimm.engine import ffi
 
 HEADER = os.path.join(os.path.dirname(os.path.dirname(__file__)), "include", "tfimm_hip.h")
@@ -49,6 +51,18 @@ def test_descriptor_validation_without_gpu():
 
 
 def test_gemm_desc_layout_matches_header():
-    """size of the ctypes mirrors == the C structs (6 pointers + 28 int32; 3 pointers + 8 int32 + float)."""
-    assert ctypes.sizeof(ffi.GemmDesc) == 6 * 8 + 28 * 4
+    """field names/order of the ctypes mirror == the C struct in the header; sizes with tail padding."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "tfimm_hip.h")).read()
+    body = hdr[hdr.index("typedef struct tfimm_gemm_desc {"):hdr.index("} tfimm_gemm_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        parts = decl.replace("*", " ").split(None, 1)[1] if not decl.startswith("const") else decl.replace("*", " ").split(None, 2)[2]
+        names += [n.strip() for n in parts.split(",")]
+    assert names == [f[0] for f in ffi.GemmDesc._fields_], names
+    assert ctypes.sizeof(ffi.GemmDesc) == (6 * 8 + 29 * 4 + 7) // 8 * 8
     assert ctypes.sizeof(ffi.AttnDesc) == 3 * 8 + 4 * 4 + 4 + 4 * 4 + 4   # 60 + tail padding to 8

@@ -84,7 +84,7 @@ def main():
 
         def launch():
             if i == idx:
-                return fn(x.data_ptr(), 1, out, npix, c_in, c_out, st)
+                return fn(x.data_ptr(), 1, *plan._input_call[1], st)
             return fn(*args, st)
         launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
