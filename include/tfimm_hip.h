@@ -165,6 +165,13 @@ typedef struct tfimm_attn_desc {
   int32_t heads, hd;
   float scale;
   int32_t window, shift, res_h, res_w;
+  const float* bias_log2; /* optional (window > 0): rel_bias with the shift mask already added and everything
+                             multiplied by log2(e), one tile per window kind:
+                             [kinds][heads][n][ceil64(n)], kinds = 1 (shift == 0) or 4 (shift > 0; kind =
+                             2 * (last window row) + (last window column) -- the only four distinct
+                             patterns of the mask of swin.py:249-273).  Built once on the host
+                             (tfimm/engine/pack.py: swin_bias_tiles); when NULL the kernel combines
+                             rel_bias and the mask itself for every workgroup. */
 } tfimm_attn_desc;
 
 TFIMM_API int tfimm_hip_attention(const tfimm_attn_desc* d, void* stream);

@@ -16,12 +16,15 @@
 //     rows are loaded and stored; the -100 shift mask is recomputed from region ids.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 struct AttnArgs {
   const bf16_t* qkv;
   bf16_t* out;
   const float* rel_bias;
+  const float* bias_log2;   // optional pre-combined (bias + mask) * log2e tiles, see tfimm_hip.h
   int batch, n_tokens, heads, hd;
   float scale;
   int window, shift, res_h, res_w;
@@ -239,6 +242,341 @@ __global__ void __launch_bounds__(256) attn_kernel(const AttnArgs p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Resident variant (sequences whose K and V^T fit in LDS): ONE workgroup per (sequence, head).
+//   * K [n][HD] (16-byte XOR-swizzled rows for HD = 64) and V^T [HD][n] are staged once -- V^T by
+//     packed 32-bit stores of key PAIRS (lane = pair: consecutive lanes, consecutive banks) -- then
+//     every wave walks its own 16-query tiles with no further workgroup synchronisation.
+//   * the softmax runs in the exp2 domain with the scale folded into one FMA per score
+//     (p = exp2(s * scale*log2e - m)), the running max is taken on raw scores, keys beyond n are
+//     masked only in the last key block, and all LDS addresses are base + immediate.  The first
+//     version of this loop issued ~320 VALU instructions per 16x64 score block and was VALU-bound
+//     (SQ_ACTIVE_INST_VALU 61 % of the kernel, MFMA 12 %).
+//   * Swin: relative-position bias AND the -100 shift mask (swin.py:175-190) are combined per
+//     workgroup into one fp32 tile [n][nkp] in LDS (pre-multiplied by log2e), from per-key region ids
+//     computed once -- the inner loop adds it with the same FMA, no divisions, no global loads.
+// ---------------------------------------------------------------------------------------------
+template <int HD>
+__device__ __forceinline__ int k_slot(int row, int chunk) {   // 16-byte slot of (key row, d chunk) in Ks
+  if (HD == 64) return row * 8 + (chunk ^ ((row >> 1) & 7));  // 128-byte rows: the GEMM swizzle
+  return row * (HD / 8 + 1) + chunk;                          // HD = 32: 80-byte padded rows
+}
+
+template <int HD>
+__device__ __forceinline__ int v_slot(int row, int chunk) {   // 16-byte slot of (key row, d chunk) in Vs
+  // row-major V, read back TRANSPOSED by ds_read_b64_tr_b16 (a 16-lane group fetches a 4-key x 16-d block
+  // as 8-byte pieces and every lane receives one d column of 4 keys); the XOR keeps the 8 rows that the
+  // two groups of a 32-lane half touch on distinct 16-byte slots of the 256-byte bank row
+  if (HD == 64) return row * 8 + (chunk ^ (((row >> 1) & 3) << 1));
+  return row * (HD / 8) + (chunk ^ (((row >> 2) & 1) << 1));
+}
+
+template <int HD, bool SWIN, int NW, int TQ>
+__global__ void __launch_bounds__(NW * 64) attn_resident_kernel(const AttnArgs p, const int nkp) {
+  constexpr int NT = NW * 64;
+  constexpr int CH = HD / 8;       // 16-byte chunks per head row
+  constexpr int KROW = HD == 64 ? 8 : CH + 1;   // slots per K row
+  constexpr int KS = HD / 32;      // MFMA k-steps over head dim
+  constexpr int DT = HD / 16;      // output d tiles
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) char smem_attn[];
+  uint4* Ks = reinterpret_cast<uint4*>(smem_attn);               // [nkp][KROW] 16-byte slots
+  uint4* Vs = Ks + (size_t)nkp * KROW;                            // [nkp][CH] 16-byte slots, row-major V
+  float* Bs = reinterpret_cast<float*>(Vs + (size_t)nkp * CH);    // SWIN: [n][nkp] bias+mask (log2 units)
+  const bool tiles = SWIN && p.bias_log2 != nullptr;            // pre-combined bias tiles: no Bs staging
+  int* Rg = reinterpret_cast<int*>(Bs + ((SWIN && !tiles) ? (size_t)p.n * nkp : 0));   // SWIN: [n] region ids
+  int* Rw = Rg + (SWIN ? p.n : 0);                                // SWIN: [n] global row of window token t
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int h = blockIdx.x % p.heads;
+  const int seq = blockIdx.x / p.heads;
+
+  // ---- Swin: global row (and region id) of every token of this window, once per workgroup -- the
+  //      roll / window_partition index map costs several integer divisions per token
+  if (SWIN) {
+    for (int t = tid; t < p.n; t += NT) {
+      int rg;
+      Rw[t] = (int)token_row<SWIN>(p, seq, t, &rg);
+      Rg[t] = rg;
+    }
+    __syncthreads();
+  }
+  auto row_of = [&](int t) -> int64_t {
+    if (SWIN) return (int64_t)Rw[t];
+    return (int64_t)seq * p.n_tokens + t;
+  };
+  // ---- Q fragments first: their global loads overlap the K / V staging below
+  // Every wave owns TQ (1 or 2) 16-query tiles, qt = wave (and wave + NW); the launcher picks NW, TQ so
+  // that NW * TQ tiles cover the sequence.  With two tiles the keys are walked ONCE for both: two
+  // independent softmax / MFMA chains per wave, K and V fragments read once.
+  int qi[TQ];
+  bool q_ok[TQ];
+  int64_t q_row[TQ];
+#pragma unroll
+  for (int u = 0; u < TQ; ++u) {
+    qi[u] = (wave + u * NW) * 16 + l15;
+    q_ok[u] = qi[u] < p.n;
+    q_row[u] = row_of(q_ok[u] ? qi[u] : 0);
+  }
+  bf16x8 qf[TQ][KS];
+#pragma unroll
+  for (int u = 0; u < TQ; ++u) {
+    const bf16_t* qp = p.qkv + q_row[u] * p.ld + h * p.hd;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = ks * 32 + g * 8;
+      uint4 uu = make_uint4(0u, 0u, 0u, 0u);
+      if (q_ok[u]) {
+        if (p.vec) {
+          if (d0 < p.hd) uu = *reinterpret_cast<const uint4*>(qp + d0);
+        } else {
+          uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const uint32_t v = (d0 + e < p.hd) ? (uint32_t)qp[d0 + e] : 0u;
+            w[e >> 1] |= v << ((e & 1) * 16);
+          }
+          uu = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+      }
+      qf[u][ks] = __builtin_bit_cast(bf16x8, uu);
+    }
+  }
+
+  // ---- stage K (16-byte stores)
+  for (int id = tid; id < nkp * CH; id += NT) {
+    const int key = id / CH, c = id - key * CH;
+    uint4 ku = make_uint4(0u, 0u, 0u, 0u);
+    if (key < p.n && c * 8 < p.hd) {
+      const int64_t row = row_of(key);
+      const bf16_t* kp = p.qkv + row * p.ld + p.dmodel + h * p.hd + c * 8;
+      if (p.vec) {
+        ku = *reinterpret_cast<const uint4*>(kp);
+      } else {
+        uint32_t kw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t kv = (c * 8 + e < p.hd) ? (uint32_t)kp[e] : 0u;
+          kw[e >> 1] |= kv << ((e & 1) * 16);
+        }
+        ku = make_uint4(kw[0], kw[1], kw[2], kw[3]);
+      }
+    }
+    Ks[k_slot<HD>(key, c)] = ku;
+  }
+  // ---- stage V row-major (16-byte stores, same coalescing as K)
+  for (int id = tid; id < nkp * CH; id += NT) {
+    const int key = id / CH, c = id - key * CH;
+    uint4 vu = make_uint4(0u, 0u, 0u, 0u);
+    if (key < p.n && c * 8 < p.hd) {
+      const int64_t row = row_of(key);
+      const bf16_t* vp = p.qkv + row * p.ld + 2 * p.dmodel + h * p.hd + c * 8;
+      if (p.vec) {
+        vu = *reinterpret_cast<const uint4*>(vp);
+      } else {
+        uint32_t vw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t vv = (c * 8 + e < p.hd) ? (uint32_t)vp[e] : 0u;
+          vw[e >> 1] |= vv << ((e & 1) * 16);
+        }
+        vu = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+      }
+    }
+    Vs[v_slot<HD>(key, c)] = vu;
+  }
+  if (SWIN && !tiles) {
+    const bool masked = p.shift > 0;
+    for (int id = tid; id < p.n * nkp; id += NT) {
+      const int q = id / nkp, key = id - q * nkp;
+      float b = 0.f;
+      if (key < p.n) {
+        if (p.rel_bias) b = p.rel_bias[((size_t)h * p.n + q) * p.n + key] * LOG2E;
+        if (masked && Rg[q] != Rg[key]) b += -100.0f * LOG2E;
+      }
+      Bs[id] = b;
+    }
+  }
+  __syncthreads();
+
+  const float cs = p.scale * LOG2E;
+  const int nkb = (p.n + 63) >> 6;
+  f32x4 o[TQ][DT];
+  float m_run[TQ], l_run[TQ];               // running max / sum, log2 units
+  const float* blane[TQ];
+#pragma unroll
+  for (int u = 0; u < TQ; ++u) {
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[u][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    m_run[u] = -1e30f;
+    l_run[u] = 0.f;
+    blane[u] = Bs + (size_t)(q_ok[u] ? qi[u] : 0) * nkp + g * 4;
+    if (tiles) {   // window kind: 2 * (last window row) + (last window column) when shifted
+      const int w = seq % p.nw;
+      const int wy = w / p.nwx, wx = w - wy * p.nwx;
+      const int kind = p.shift > 0 ? 2 * (wy == p.nw / p.nwx - 1 ? 1 : 0) + (wx == p.nwx - 1 ? 1 : 0) : 0;
+      blane[u] = p.bias_log2 + (((size_t)kind * p.heads + h) * p.n + (q_ok[u] ? qi[u] : 0)) * nkp + g * 4;
+    }
+  }
+  const bool two = TQ == 2 && (wave + NW) * 16 < p.n;   // second tile present (wave-uniform)
+
+  if (wave * 16 < p.n) {
+    for (int kb = 0; kb < nkb; ++kb) {
+      // ---- raw scores S^T[key][q] of the 4 key tiles of this block, both query tiles
+      f32x4 acc[TQ][4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int u = 0; u < TQ; ++u) acc[u][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 kf = __builtin_bit_cast(bf16x8, Ks[k_slot<HD>(kb * 64 + t * 16 + l15, ks * 4 + g)]);
+#pragma unroll
+          for (int u = 0; u < TQ; ++u)
+            if (u == 0 || two) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], acc[u][t], 0, 0, 0);
+        }
+      }
+      bf16x8 pf[TQ][2];
+#pragma unroll
+      for (int u = 0; u < TQ; ++u) {
+        if (u == 1 && !two) break;
+        float sc[16];
+        if (SWIN) {   // log2-domain logits: s * scale * log2e + (bias + mask) * log2e
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float4 b4 = *reinterpret_cast<const float4*>(blane[u] + kb * 64 + t * 16);
+            sc[t * 4 + 0] = fmaf(acc[u][t][0], cs, b4.x); sc[t * 4 + 1] = fmaf(acc[u][t][1], cs, b4.y);
+            sc[t * 4 + 2] = fmaf(acc[u][t][2], cs, b4.z); sc[t * 4 + 3] = fmaf(acc[u][t][3], cs, b4.w);
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[t * 4 + r] = acc[u][t][r];
+        }
+        if (kb * 64 + 64 > p.n) {   // last block: keys beyond n never win the max and get p = 0
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (kb * 64 + t * 16 + g * 4 + r >= p.n) sc[t * 4 + r] = -__builtin_inff();
+        }
+        // ---- online softmax, exp2 domain.  Non-Swin: sc are RAW scores, the scale rides on the FMA.
+        const float mul = SWIN ? 1.f : cs;
+        float mloc = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) mloc = fmaxf(fmaxf(mloc, sc[i]), sc[i + 1]);
+        mloc = fmaxf(mloc, sc[15]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run[u], mloc * mul);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          sc[i] = __builtin_amdgcn_exp2f(fmaf(sc[i], mul, -m_new));
+          psum += sc[i];
+        }
+        l_run[u] = l_run[u] * alpha + psum;
+        m_run[u] = m_new;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) o[u][i] *= alpha;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          uint4 pu;
+          pu.x = pack_bf2(sc[8 * s2 + 0], sc[8 * s2 + 1]);
+          pu.y = pack_bf2(sc[8 * s2 + 2], sc[8 * s2 + 3]);
+          pu.z = pack_bf2(sc[8 * s2 + 4], sc[8 * s2 + 5]);
+          pu.w = pack_bf2(sc[8 * s2 + 6], sc[8 * s2 + 7]);
+          pf[u][s2] = __builtin_bit_cast(bf16x8, pu);
+        }
+      }
+      // ---- O^T[d][q] += V^T[d][key] . P^T[key][q]   (V^T fragments read once for both tiles)
+      typedef __attribute__((ext_vector_type(4))) short s16x4;
+      typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          // lane (l15, g) fetches the 8-byte piece (key 4g + l15/4, d 4*(l15%4)..+3) of the two 16-key
+          // tiles and receives keys 4g..4g+3 at d = l15 of each: exactly the MFMA A fragment of V^T
+          const int krow = kb * 64 + g * 4 + (l15 >> 2);
+          const int chunk = dt * 2 + ((l15 & 3) >> 1);
+          const char* base = reinterpret_cast<const char*>(Vs) + (l15 & 1) * 8;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (lds_s16x4_ptr)(base + (size_t)v_slot<HD>(krow + (2 * s2) * 16, chunk) * 16));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (lds_s16x4_ptr)(base + (size_t)v_slot<HD>(krow + (2 * s2 + 1) * 16, chunk) * 16));
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, cat);
+#pragma unroll
+          for (int u = 0; u < TQ; ++u)
+            if (u == 0 || two) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u][s2], o[u][dt], 0, 0, 0);
+        }
+      }
+    }
+
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+      float l_tot = l_run[u] + __shfl_xor(l_run[u], 16, 64);
+      l_tot += __shfl_xor(l_tot, 32, 64);
+      if (q_ok[u]) {
+        const float inv = 1.f / l_tot;
+        bf16_t* op = p.out + q_row[u] * p.dmodel + h * p.hd;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int d0 = dt * 16 + g * 4;
+          if (d0 >= p.hd) continue;
+          const float v0 = o[u][dt][0] * inv, v1 = o[u][dt][1] * inv, v2 = o[u][dt][2] * inv, v3 = o[u][dt][3] * inv;
+          if (p.vec) {
+            *reinterpret_cast<uint2*>(op + d0) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
+          } else {
+            const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (d0 + e < p.hd) op[d0 + e] = (bf16_t)f2bf(vv[e]);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int HD>
+static size_t attn_resident_lds(int n, bool swin, bool tiles) {
+  const int nkp = (n + 63) / 64 * 64;
+  const int krow = HD == 64 ? 8 : HD / 8 + 1;
+  size_t b = (size_t)nkp * krow * 16 + (size_t)nkp * (HD / 8) * 16;
+  if (swin) b += (tiles ? 0 : (size_t)n * nkp * sizeof(float)) + 2 * (size_t)n * sizeof(int);
+  return b;
+}
+
+template <int HD, bool SWIN, int NW, int TQ>
+static int launch_attn_resident(const AttnArgs& a, int64_t nseq, hipStream_t st) {
+  const int nkp = (a.n + 63) / 64 * 64;
+  const size_t lds = attn_resident_lds<HD>(a.n, SWIN, a.bias_log2 != nullptr);
+  static bool attr_done = false;
+  if (!attr_done) {
+    TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)attn_resident_kernel<HD, SWIN, NW, TQ>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  TFIMM_LAUNCH((attn_resident_kernel<HD, SWIN, NW, TQ>), dim3((unsigned)(nseq * a.heads)), dim3(NW * 64), lds, st, a, nkp);
+  return 0;
+}
+
+// waves x query tiles per wave that cover ceil(n / 16) tiles: <= 4 -> 4x1, <= 8 -> 8x1, <= 16 -> 8x2
+template <int HD, bool SWIN>
+static int launch_attn_resident_any(const AttnArgs& a, int64_t nseq, hipStream_t st) {
+  const int tiles = (a.n + 15) / 16;
+  if (tiles <= 4) return launch_attn_resident<HD, SWIN, 4, 1>(a, nseq, st);
+  if (tiles <= 8) return launch_attn_resident<HD, SWIN, 8, 1>(a, nseq, st);
+  return launch_attn_resident<HD, SWIN, 8, 2>(a, nseq, st);
+}
+
 }  // namespace
 
 extern "C" int tfimm_hip_attention(const tfimm_attn_desc* dp, void* stream) {
@@ -250,6 +588,7 @@ extern "C" int tfimm_hip_attention(const tfimm_attn_desc* dp, void* stream) {
   if (d.hd > 64) TFIMM_FAIL(TFIMM_EUNSUP, "attention: head dim %d > 64 not built", d.hd);
   AttnArgs a;
   a.qkv = (const bf16_t*)d.qkv; a.out = (bf16_t*)d.out; a.rel_bias = d.rel_bias;
+  a.bias_log2 = d.window > 0 ? d.bias_log2 : nullptr;
   a.batch = d.batch; a.n_tokens = d.n_tokens; a.heads = d.heads; a.hd = d.hd; a.scale = d.scale;
   a.window = d.window; a.shift = d.shift; a.res_h = d.res_h; a.res_w = d.res_w;
   a.dmodel = d.heads * d.hd; a.ld = 3 * a.dmodel;
@@ -272,6 +611,21 @@ extern "C" int tfimm_hip_attention(const tfimm_attn_desc* dp, void* stream) {
   if (nblocks > 0x7fffffffLL) TFIMM_FAIL(TFIMM_EINVAL, "attention: grid too large");
   const dim3 grid((unsigned)nblocks), block(256);
   hipStream_t st = (hipStream_t)stream;
+  {
+    // K + V^T (+ Swin bias tile) of one (sequence, head) resident in LDS (<= 80 KiB: two workgroups per CU)
+    const bool tl = d.window > 0 && d.bias_log2 != nullptr;
+    const size_t lds = d.hd <= 32 ? attn_resident_lds<32>(a.n, d.window > 0, tl) : attn_resident_lds<64>(a.n, d.window > 0, tl);
+    static int use_resident = -1;
+    if (use_resident < 0) {
+      const char* e = getenv("TFIMM_ATTN_NO_RESIDENT");
+      use_resident = (e && e[0] == '1') ? 0 : 1;
+    }
+    if (use_resident && lds <= 80 * 1024 && a.n <= 256 && nseq * d.heads <= 0x7fffffffLL) {
+      if (d.window > 0)
+        return d.hd <= 32 ? launch_attn_resident_any<32, true>(a, nseq, st) : launch_attn_resident_any<64, true>(a, nseq, st);
+      return d.hd <= 32 ? launch_attn_resident_any<32, false>(a, nseq, st) : launch_attn_resident_any<64, false>(a, nseq, st);
+    }
+  }
   if (d.window > 0) {
     if (d.hd <= 32) TFIMM_LAUNCH((attn_kernel<32, true>), grid, block, 0, st, a);
     else TFIMM_LAUNCH((attn_kernel<64, true>), grid, block, 0, st, a);

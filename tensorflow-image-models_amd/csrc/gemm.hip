@@ -107,7 +107,7 @@ int pick_dma_tile(const tfimm_gemm_desc& d) {
 // ceil(tiles / slots) rounds; score = efficiency x useful area x fill of those rounds.
 int pick_stream_tile(const tfimm_gemm_desc& d, const int* occ) {
   if (d.tile_hint > 20 && d.tile_hint <= 20 + TFIMM_GEMM_STREAM_NUM_TILES) return d.tile_hint - 21;
-  static const double eff[TFIMM_GEMM_STREAM_NUM_TILES] = {1.00, 0.90, 0.75, 0.70, 0.55, 0.90};
+  static const double eff[TFIMM_GEMM_STREAM_NUM_TILES] = {1.00, 0.90, 0.75, 0.70, 0.55, 0.90, 0.75};
   const int cus = num_cu();
   int best = 2;
   double best_score = -1.0;

@@ -499,5 +499,6 @@ struct StreamTileCfg {
   X(2, 128, 128, 2, 2)             \
   X(3, 256, 64, 4, 2)              \
   X(4, 128, 64, 2, 2)              \
-  X(5, 128, 256, 2, 4)
-#define TFIMM_GEMM_STREAM_NUM_TILES 6
+  X(5, 128, 256, 2, 4)             \
+  X(6, 256, 64, 4, 1)
+#define TFIMM_GEMM_STREAM_NUM_TILES 7

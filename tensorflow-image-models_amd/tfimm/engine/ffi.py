@@ -44,6 +44,7 @@ class AttnDesc(C.Structure):
         ("batch", C.c_int32), ("n_tokens", C.c_int32), ("heads", C.c_int32), ("hd", C.c_int32),
         ("scale", C.c_float),
         ("window", C.c_int32), ("shift", C.c_int32), ("res_h", C.c_int32), ("res_w", C.c_int32),
+        ("bias_log2", C.c_void_p),
     ]
 
 

@@ -381,6 +381,9 @@ class Builder:
         consts = {}
         if rel_bias is not None:
             consts["rel_bias"] = p.new_const(np.ascontiguousarray(rel_bias, dtype=np.float32), name + ":rel_bias")
+            if window:   # bias + shift mask, combined once on the host, per window kind
+                consts["bias_log2"] = p.new_const(pack.swin_bias_tiles(np.asarray(rel_bias, np.float32), window, shift),
+                                                  name + ":bias_log2")
         n = window * window if window else qkv.rows
         nseq = (qkv.rows // n)
         p.add("attention", [qkv], out, consts, cite=cite, heads=heads, hd=hd, scale=float(scale),
@@ -601,6 +604,7 @@ class Plan:
                 d.qkv = self.tptr(op.inputs[0])
                 d.out = self.tptr(op.output)
                 d.rel_bias = self.cptr(op.consts.get("rel_bias"))
+                d.bias_log2 = self.cptr(op.consts.get("bias_log2"))
                 d.batch, d.n_tokens, d.heads, d.hd = B, a["n_tokens"], a["heads"], a["hd"]
                 d.scale = a["scale"]
                 d.window, d.shift, d.res_h, d.res_w = a["window"], a["shift"], a["res_h"], a["res_w"]

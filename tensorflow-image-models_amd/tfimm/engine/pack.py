@@ -95,3 +95,28 @@ def pack_depthwise(kernel: np.ndarray, scale: Optional[np.ndarray], shift: Optio
         w = w * scale.reshape(1, c)
     b = None if shift is None else np.ascontiguousarray(shift, dtype=np.float32)
     return np.ascontiguousarray(w), b
+
+
+def swin_bias_tiles(rel_bias: np.ndarray, window: int, shift: int) -> np.ndarray:
+    """(rel_bias + shift mask) * log2(e) per window kind -> fp32 [kinds][heads][n][ceil64(n)].
+
+    ``rel_bias``: gathered relative_position_bias [heads][n][n] (swin.py:175-184).  The mask of
+    swin.py:249-273 gives a token of the shifted frame the region id 3*rh + rw with
+    rh = 0 / 1 / 2 for rows in [0, H-ws) / [H-ws, H-shift) / [H-shift, H) (rw alike), and adds -100
+    between tokens of different regions.  Inside one window only the LAST window row / column sees
+    more than one region, so there are four distinct patterns: kind = 2*last_row + last_col.
+    """
+    heads, n, _ = rel_bias.shape
+    nkp = ceil_to(n, 64)
+    kinds = 4 if shift > 0 else 1
+    log2e = 1.4426950408889634
+    out = np.zeros((kinds, heads, n, nkp), dtype=np.float32)
+    ty, tx = np.divmod(np.arange(n), window)
+    for kind in range(kinds):
+        last_row, last_col = kind >> 1, kind & 1
+        rh = np.where(ty < window - shift, 1, 2) if last_row else np.zeros(n, dtype=np.int64)
+        rw = np.where(tx < window - shift, 1, 2) if last_col else np.zeros(n, dtype=np.int64)
+        reg = rh * 3 + rw
+        mask = np.where(reg[:, None] != reg[None, :], -100.0, 0.0) if shift > 0 else 0.0
+        out[kind, :, :, :n] = (rel_bias.astype(np.float64) + mask) * log2e
+    return out

@@ -94,15 +94,15 @@ def _gemm_case(M, K, N, *, act="", bias=True, residual=False, act_after_res=Fals
     return _err(got, ref), (TOL_F32 if out_f32 else TOL_BF16)
 
 
-# tile hints: 0 auto, 1..6 register-staged tiles, 11..16 LDS-DMA tiles, 21..26 persistent LDS-DMA tiles
-for _t in list(range(0, 7)) + list(range(11, 17)) + list(range(21, 27)):
+# tile hints: 0 auto, 1..6 register-staged tiles, 11..16 LDS-DMA tiles, 21..27 persistent LDS-DMA tiles
+for _t in list(range(0, 7)) + list(range(11, 17)) + list(range(21, 28)):
     CASES[f"gemm_tile{_t:02d}_256x192x320"] = (lambda t=_t: _gemm_case(256, 192, 320, tile=t, seed=1))
     CASES[f"gemm_tile{_t:02d}_ragged_333x200x150_gelu_res"] = (
         lambda t=_t: _gemm_case(333, 200, 150, act="gelu", residual=True, tile=t, seed=2))
     CASES[f"gemm_tile{_t:02d}_600x320x520_relu_after_res_f32"] = (
         lambda t=_t: _gemm_case(600, 320, 520, act="relu", residual=True, act_after_res=True, out_f32=True, tile=t,
                                 seed=3))
-for _t in range(21, 27):
+for _t in range(21, 28):
     # more tiles than resident workgroups: every persistent workgroup walks several tiles (ragged M, N, K)
     CASES[f"gemm_stream_multiround_tile{_t:02d}"] = (
         lambda t=_t: _gemm_case(40000, 200, 520, act="gelu", residual=True, tile=t, seed=50 + t))
@@ -219,7 +219,7 @@ CASES["conv3x3_s2_same_even"] = lambda: _conv_case(2, 20, 20, 16, 24, 3, 2, "sam
 CASES["conv3x3_scalar_cin6"] = lambda: _conv_case(2, 8, 8, 6, 10, 3, 1, 1, act="relu", seed=39)
 CASES["conv3x3_scalar_cin2_s2"] = lambda: _conv_case(3, 9, 9, 2, 4, 3, 2, 1, seed=40)
 CASES["conv1ch_8x8_patch"] = lambda: _conv_case(2, 32, 32, 1, 4, 8, 8, 0, bn=False, seed=41)
-for _t in (1, 2, 3, 4, 5, 6, 11, 12, 13, 14, 15, 16, 21, 22, 23, 24, 25, 26):
+for _t in (1, 2, 3, 4, 5, 6, 11, 12, 13, 14, 15, 16, 21, 22, 23, 24, 25, 26, 27):
     CASES[f"conv3x3_tile{_t:02d}"] = (lambda t=_t: _conv_case(2, 16, 16, 64, 96, 3, 1, 1, act="relu", seed=42, tile=t))
     CASES[f"conv3x3_s2_res_tile{_t:02d}"] = (
         lambda t=_t: _conv_case(3, 15, 13, 40, 72, 3, 2, 1, act="relu", residual=True, seed=43, tile=t))
@@ -350,7 +350,7 @@ def _swin_ref(x_qkv, B, Hr, Wr, heads, hd, ws, shift, table):
     return o.reshape(B * Hr * Wr, C).numpy(), index
 
 
-def _swin_case(B, Hr, Wr, heads, hd, ws, shift, seed):
+def _swin_case(B, Hr, Wr, heads, hd, ws, shift, seed, tiles=False):
     import hip_ops as H
     r = _rng(seed)
     C = heads * hd
@@ -359,8 +359,10 @@ def _swin_case(B, Hr, Wr, heads, hd, ws, shift, seed):
     ref, index = _swin_ref(qkv, B, Hr, Wr, heads, hd, ws, shift, table)
     n = ws * ws
     bias = table[index.reshape(-1)].reshape(n, n, heads).transpose(2, 0, 1).copy()
+    # tiles: bias + shift mask pre-combined on the host per window kind (what the engine passes)
+    bl2 = H.dev_f32(pack.swin_bias_tiles(bias, ws, shift)) if tiles else None
     got = H.attention(H.dev_bf16(qkv), B, Hr * Wr, heads, hd, hd ** -0.5, window=ws, shift=shift, res=(Hr, Wr),
-                      rel_bias=H.dev_f32(bias))
+                      rel_bias=H.dev_f32(bias), bias_log2=bl2)
     H.sync()
     return _err(_cpu(got), ref), 1.5e-2
 
@@ -371,6 +373,15 @@ CASES["swin_w7_shift3_28x14_rect"] = lambda: _swin_case(1, 28, 14, 2, 32, 7, 3, 
 CASES["swin_w4_shift2_8x8_hd4"] = lambda: _swin_case(2, 8, 8, 1, 4, 4, 2, 73)
 CASES["swin_w12_shift6_24x24"] = lambda: _swin_case(1, 24, 24, 2, 32, 12, 6, 74)
 CASES["swin_w7_single_window"] = lambda: _swin_case(3, 7, 7, 2, 32, 7, 0, 75)
+CASES["swin_tiles_w7_noshift_14x14"] = lambda: _swin_case(2, 14, 14, 4, 32, 7, 0, 76, tiles=True)
+CASES["swin_tiles_w7_shift3_14x14"] = lambda: _swin_case(2, 14, 14, 4, 32, 7, 3, 77, tiles=True)
+CASES["swin_tiles_w7_shift3_28x14_rect"] = lambda: _swin_case(1, 28, 14, 2, 32, 7, 3, 78, tiles=True)
+CASES["swin_tiles_w7_shift3_21x35"] = lambda: _swin_case(2, 21, 35, 3, 32, 7, 3, 79, tiles=True)
+CASES["swin_tiles_w4_shift2_8x8_hd4"] = lambda: _swin_case(2, 8, 8, 1, 4, 4, 2, 80, tiles=True)
+CASES["swin_tiles_w12_shift6_24x24"] = lambda: _swin_case(1, 24, 24, 2, 32, 12, 6, 81, tiles=True)
+CASES["swin_tiles_w7_shift3_single_row"] = lambda: _swin_case(2, 7, 21, 2, 32, 7, 3, 82, tiles=True)
+CASES["attn_256_exact"] = lambda: _attn_case(1, 256, 2, 64, 68)
+CASES["attn_130_hd32"] = lambda: _attn_case(2, 130, 2, 32, 69)
 
 
 @case("maxpool_3x3_s2_p1")

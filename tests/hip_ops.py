@@ -93,10 +93,11 @@ def layernorm(x, gamma, beta, eps, rows=None, d=None, xs=None, ys=None, out=None
     return out
 
 
-def attention(qkv, batch, n_tokens, heads, hd, scale, window=0, shift=0, res=(0, 0), rel_bias=None):
+def attention(qkv, batch, n_tokens, heads, hd, scale, window=0, shift=0, res=(0, 0), rel_bias=None, bias_log2=None):
     out = torch.empty(batch * n_tokens, heads * hd, dtype=torch.bfloat16, device=DEV)
     d = ffi.AttnDesc()
     d.qkv, d.out, d.rel_bias = ptr(qkv), ptr(out), ptr(rel_bias)
+    d.bias_log2 = ptr(bias_log2)
     d.batch, d.n_tokens, d.heads, d.hd, d.scale = batch, n_tokens, heads, hd, float(scale)
     d.window, d.shift, d.res_h, d.res_w = window, shift, res[0], res[1]
     ffi.check(lib.tfimm_hip_attention(C.byref(d), stream()), "attention")

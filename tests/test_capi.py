@@ -65,4 +65,5 @@ def test_gemm_desc_layout_matches_header():
         names += [n.strip() for n in parts.split(",")]
     assert names == [f[0] for f in ffi.GemmDesc._fields_], names
     assert ctypes.sizeof(ffi.GemmDesc) == (6 * 8 + 29 * 4 + 7) // 8 * 8
-    assert ctypes.sizeof(ffi.AttnDesc) == 3 * 8 + 4 * 4 + 4 + 4 * 4 + 4   # 60 + tail padding to 8
+    # 3 pointers, 4 int32, float, 4 int32 (= 60, padded to 64 for the pointer that follows), 1 pointer
+    assert ctypes.sizeof(ffi.AttnDesc) == 64 + 8
