@@ -298,7 +298,8 @@ class Builder:
     def dense(self, x: TRef, kernel: str, bias: Optional[str] = None, *, act="",
               residual: Optional[TRef] = None, out_f32=False, row_select: Optional[Tuple[int, int]] = None,
               in_cols: Optional[Tuple[int, int]] = None,
-              out: Optional[TRef] = None, out_col: int = 0, cite="", name="") -> TRef:
+              out: Optional[TRef] = None, out_col: int = 0, out_scale: Optional[str] = None,
+              cite="", name="") -> TRef:
         """tf.keras.layers.Dense (+ activation, + residual add).
 
         ``row_select=(first_row, count)`` applies the layer to ``count`` rows per image
@@ -308,12 +309,23 @@ class Builder:
         """
         p = self.p
         k = self.wget(kernel)
+        if k.ndim == 4:     # 1x1 Conv2D used as a Dense (ConvMLP, layers/transformers.py:238-252)
+            assert k.shape[0] == 1 and k.shape[1] == 1
+            k = k[0, 0]
         kin, kout = k.shape
+        bvec_in = None if bias is None else self.wget(bias)
+        if out_scale is not None:
+            # per-output-channel scale behind the layer (LayerScale, convnext.py:228) folded into it:
+            # g * (x W + b) = x (W g) + b g
+            g = self.wget(out_scale).reshape(1, kout)
+            k = k * g
+            if bvec_in is not None:
+                bvec_in = bvec_in * g.reshape(kout)
         if in_cols is None:
             assert kin == x.C, f"{kernel}: in={kin} but tensor has C={x.C}"
         else:
             assert in_cols[1] == kin and in_cols[0] + kin <= x.C
-        wt, bvec = pack.pack_dense(k, None if bias is None else self.wget(bias))
+        wt, bvec = pack.pack_dense(k, bvec_in)
         rows = x.rows
         attrs = dict(M=rows, N=kout, K=kin, K_true=kin, mode=0, lda=x.C, act=act, act_after_res=False,
                      out_f32=1 if out_f32 else 0, res_mod=0, remap=None, ldw=wt.shape[1],
@@ -326,7 +338,8 @@ class Builder:
         if in_cols is not None:
             attrs["a_byte_offset"] = attrs.get("a_byte_offset", 0) + in_cols[0] * 2
         if out is None:
-            out = p.new_tensor(rows, kout, dtype="f32" if out_f32 else "bf16", name=name or kernel)
+            sp = (x.H, x.W) if (row_select is None and x.H * x.W == rows) else (0, 0)   # Dense keeps the spatial grid
+            out = p.new_tensor(rows, kout, sp[0], sp[1], dtype="f32" if out_f32 else "bf16", name=name or kernel)
         else:
             attrs["out_col"] = out_col
         attrs["ldc"] = out.C

@@ -19,7 +19,8 @@ for p in (ROOT, os.path.join(ROOT, "tensorflow-image-models_amd"), os.path.join(
 MODELS = [("vit_test_model", 2), ("deit_test_model", 2), ("vit_hd64_test_model", 2), ("resnet_test_model_1", 2),
           ("resnet_test_model_2", 2), ("resnet50_mini_test_model", 2), ("seresnet_test_model", 2),
           ("swin_test_model", 2), ("swin_shift_test_model", 2), ("efficientnet_test_model", 2),
-          ("efficientnet_same_test_model", 2), ("vit_tiny_patch16_224", 1)]
+          ("efficientnet_same_test_model", 2), ("convnext_odd_test_model", 2), ("convnext_wide_test_model", 2),
+          ("vit_tiny_patch16_224", 1)]
 
 
 def main():

@@ -6,6 +6,7 @@ tests/models/architectures.py:33-361: tiny configs registered through the real
 assumptions.  The second block closes coverage holes the survey found in the reference's
 minis: head dim 64, default 7x7 stem + Bottleneck + downsample_conv, SE.
 """
+from tfimm.architectures.convnext import ConvNeXt, ConvNeXtConfig
 from tfimm.architectures.efficientnet import EfficientNet, EfficientNetConfig
 from tfimm.architectures.resnet import ResNet, ResNetConfig
 from tfimm.architectures.swin import SwinTransformer, SwinTransformerConfig
@@ -77,6 +78,26 @@ if not is_model("vit_test_model"):
     def resnet50_mini_test_model():
         return ResNet, ResNetConfig(name="resnet50_mini_test_model", nb_classes=10, input_size=(64, 64),
                                     block="bottleneck", nb_blocks=(1, 2, 1, 1), nb_channels=(8, 16, 24, 32))
+
+    @register_model
+    def convnext_test_model():
+        """Same hyper-parameters as the reference's mini (tests/models/architectures.py)."""
+        return ConvNeXt, ConvNeXtConfig(name="convnext_test_model", nb_classes=12, input_size=(32, 32), embed_dim=(4, 4, 4, 4),
+                                        nb_blocks=(1, 1, 1, 1))
+
+    @register_model
+    def convnext_odd_test_model():
+        """Channel counts that are not multiples of 8 (element-wise kernel paths) but wide enough for a
+        LayerNorm over bf16-stored activations to be well conditioned (the 4-channel reference mini is
+        not: one bf16 ulp moves a value normalised over 4 channels by tens of percent)."""
+        return ConvNeXt, ConvNeXtConfig(name="convnext_odd_test_model", nb_classes=12, input_size=(64, 64),
+                                        embed_dim=(12, 20, 28, 36), nb_blocks=(1, 1, 1, 1))
+
+    @register_model
+    def convnext_wide_test_model():
+        """16-byte-aligned channel counts (vector kernels), ConvMLP blocks, odd input size, 3 stages."""
+        return ConvNeXt, ConvNeXtConfig(name="convnext_wide_test_model", nb_classes=10, input_size=(72, 56),
+                                        embed_dim=(16, 32, 64), nb_blocks=(2, 1, 2), conv_mlp_block=True)
 
     @register_model
     def seresnet_test_model():
