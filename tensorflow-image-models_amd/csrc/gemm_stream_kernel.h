@@ -58,65 +58,6 @@ struct StreamGeom {
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit in LDS");
 };
 
-// Epilogue activation, branch-light (reference act_layer_factory, layers/factory.py:6-13):
-//   clamp class   none / relu / relu6 :   v = min(max(v, lo), hi)                 (always executed)
-//   sigmoid class swish / sigmoid / tanh: s = 1/(1+exp(-k v)); v = a v s + b s + c
-//   gelu (exact erf form; erf by Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7)
-struct ActParams {
-  float lo, hi, k, a, b, c;
-  int cls;
-};
-__device__ __forceinline__ ActParams make_act(int act) {
-  ActParams q;
-  q.lo = -__builtin_inff(); q.hi = __builtin_inff(); q.k = 1.f; q.a = 0.f; q.b = 0.f; q.c = 0.f; q.cls = 0;
-  switch (act) {
-    case TFIMM_ACT_RELU: q.lo = 0.f; break;
-    case TFIMM_ACT_RELU6: q.lo = 0.f; q.hi = 6.f; break;
-    case TFIMM_ACT_SWISH: q.cls = 1; q.a = 1.f; break;
-    case TFIMM_ACT_SIGMOID: q.cls = 1; q.b = 1.f; break;
-    case TFIMM_ACT_TANH: q.cls = 1; q.k = 2.f; q.b = 2.f; q.c = -1.f; break;
-    case TFIMM_ACT_GELU: q.cls = 2; break;
-    default: break;
-  }
-  return q;
-}
-__device__ __forceinline__ float gelu_erf(float v) {
-  const float xx = v * 0.70710678118654752f;
-  const float ax = fabsf(xx);
-  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
-  float poly = 1.061405429f;
-  poly = poly * t - 1.453152027f;
-  poly = poly * t + 1.421413741f;
-  poly = poly * t - 0.284496736f;
-  poly = poly * t + 0.254829592f;
-  const float erfa = 1.f - poly * t * __expf(-ax * ax);
-  return 0.5f * v * (1.f + copysignf(erfa, xx));
-}
-__device__ __forceinline__ float act1(float v, const ActParams& q) {
-  v = fminf(fmaxf(v, q.lo), q.hi);
-  if (q.cls == 1) {
-    const float sgm = __builtin_amdgcn_rcpf(1.f + __expf(-q.k * v));
-    v = q.a * v * sgm + (q.b * sgm + q.c);
-  } else if (q.cls == 2) {
-    v = gelu_erf(v);
-  }
-  return v;
-}
-__device__ __forceinline__ void act8(float* v, const ActParams& q) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(v[e], q.lo), q.hi);
-  if (q.cls == 1) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float sgm = __builtin_amdgcn_rcpf(1.f + __expf(-q.k * v[e]));
-      v[e] = q.a * v[e] * sgm + (q.b * sgm + q.c);
-    }
-  } else if (q.cls == 2) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-  }
-}
-
 template <int BM, int BN, int WAVES_M, int WAVES_N, int KMODE, bool VEC>
 __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(const GemmStreamArgs pa) {
   using G = StreamGeom<BM, BN, WAVES_M, WAVES_N>;

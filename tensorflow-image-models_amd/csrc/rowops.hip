@@ -4,6 +4,9 @@
 // whenever the channel count allows it.  Reference call sites: include/tfimm_hip.h.
 #include "common.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 #include <cstdarg>
 #include <cstdio>
 
@@ -343,26 +346,47 @@ __global__ void __launch_bounds__(256) dwconv_kernel(const bf16_t* x, const floa
   }
 }
 
-// Strip kernel (C % 8 == 0, k/stride known at compile time): a thread owns 8 channels x PX
+// Strip kernel (C % CV == 0, k/stride known at compile time): a thread owns CV (8 or 4) channels x PX
 // horizontally adjacent output pixels.  Per filter row it loads each needed input column ONCE
-// (16 B) and feeds every (pixel, tap) pair that touches it, with that row's weights held in
+// (16 / 8 B) and feeds every (pixel, tap) pair that touches it, with that row's weights held in
 // registers -- k*k/PX-fold fewer loads than one-output-per-thread.  Consecutive lanes own
 // consecutive channel groups, so every load/store instruction covers contiguous NHWC bytes.
-// The SE squeeze (sum of the stored, bf16-rounded outputs per image and channel) is reduced in
-// LDS ([8][C/8], conflict-free ds_add) and leaves the block as ONE global atomic per channel.
-template <int K, int S, int PX>
+// Everything is branch-free: out-of-image rows/columns are clamped addresses + zeroed values, the
+// activation uses wave-uniform parameters.  The SE squeeze (sum of the stored, bf16-rounded outputs
+// per image and channel) is reduced in LDS ([CV][C/CV], conflict-free ds_add) and leaves the block
+// as ONE global atomic per channel.
+template <int CV>
+struct dwvec;
+template <>
+struct dwvec<8> { typedef uint4 type; };
+template <>
+struct dwvec<4> { typedef uint2 type; };
+
+template <int CV>
+__device__ __forceinline__ void dw_unpack(const typename dwvec<CV>::type& u, float* f) {
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(&u);
+#pragma unroll
+  for (int i = 0; i < CV / 2; ++i) {
+    f[2 * i] = bf2f(w[i] & 0xffffu);
+    f[2 * i + 1] = bf2f(w[i] >> 16);
+  }
+}
+
+template <int K, int S, int PX, int CV>
 __global__ void __launch_bounds__(256) dwconv_strip_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, bf16_t* __restrict__ y,
                                                            float* sum_out, int H, int W, int C, int pad_t, int pad_l,
                                                            int OH, int OW, int act) {
-  extern __shared__ float lsum[];  // [8][cgs]
+  typedef typename dwvec<CV>::type vec_t;
+  extern __shared__ float lsum[];  // [CV][cgs]
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
-  const int cgs = C >> 3;
+  const int cgs = C / CV;
   const int sx = (OW + PX - 1) / PX;
   const int items = OH * sx * cgs;
+  const ActParams actp = make_act(act);
   if (sum_out) {
-    for (int i = tid; i < 8 * cgs; i += 256) lsum[i] = 0.f;
+    for (int i = tid; i < CV * cgs; i += 256) lsum[i] = 0.f;
     __syncthreads();
   }
   constexpr int COLS = (PX - 1) * S + K;
@@ -370,88 +394,311 @@ __global__ void __launch_bounds__(256) dwconv_strip_kernel(const bf16_t* __restr
     const int cg = item % cgs;
     const int t = item / cgs;
     const int sxi = t % sx, oy = t / sx;
-    const int ox0 = sxi * PX, c0 = cg * 8;
-    float acc[PX][8];
-    {
-      float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (bias) {
-        const float4 b0 = *reinterpret_cast<const float4*>(bias + c0);
-        const float4 b1 = *reinterpret_cast<const float4*>(bias + c0 + 4);
-        b8[0] = b0.x; b8[1] = b0.y; b8[2] = b0.z; b8[3] = b0.w; b8[4] = b1.x; b8[5] = b1.y; b8[6] = b1.z; b8[7] = b1.w;
-      }
+    const int ox0 = sxi * PX, c0 = cg * CV;
+    float acc[PX][CV];
 #pragma unroll
-      for (int px = 0; px < PX; ++px)
+    for (int e = 0; e < CV; ++e) {
+      const float be = bias ? bias[c0 + e] : 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[px][e] = b8[e];
+      for (int px = 0; px < PX; ++px) acc[px][e] = be;
     }
     const int ixb = ox0 * S - pad_l;
+    const bf16_t* ximg = x + (size_t)b * H * W * C + c0;
 #pragma unroll 1
     for (int ky = 0; ky < K; ++ky) {
       const int iy = oy * S - pad_t + ky;
-      if ((unsigned)iy >= (unsigned)H) continue;
-      float wr[K][8];
+      const bool rok = (unsigned)iy < (unsigned)H;
+      const int iyc = rok ? iy : 0;
+      float wr[K][CV];
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
         const float* wp = w + (size_t)(ky * K + kx) * C + c0;
-        const float4 w0 = *reinterpret_cast<const float4*>(wp);
-        const float4 w1 = *reinterpret_cast<const float4*>(wp + 4);
-        wr[kx][0] = w0.x; wr[kx][1] = w0.y; wr[kx][2] = w0.z; wr[kx][3] = w0.w;
-        wr[kx][4] = w1.x; wr[kx][5] = w1.y; wr[kx][6] = w1.z; wr[kx][7] = w1.w;
+#pragma unroll
+        for (int q = 0; q < CV / 4; ++q) {
+          const float4 w4 = *reinterpret_cast<const float4*>(wp + 4 * q);
+          wr[kx][4 * q + 0] = w4.x; wr[kx][4 * q + 1] = w4.y; wr[kx][4 * q + 2] = w4.z; wr[kx][4 * q + 3] = w4.w;
+        }
       }
-      const bf16_t* xrow = x + ((size_t)((size_t)b * H + iy) * W) * C + c0;
+      const bf16_t* xrow = ximg + (size_t)iyc * W * C;
+      vec_t raw[COLS];
 #pragma unroll
       for (int col = 0; col < COLS; ++col) {
         const int ix = ixb + col;
-        if ((unsigned)ix < (unsigned)W) {
-          float v[8];
-          unpack8(*reinterpret_cast<const uint4*>(xrow + (size_t)ix * C), v);
+        const int ixc = min(max(ix, 0), W - 1);
+        raw[col] = *reinterpret_cast<const vec_t*>(xrow + (size_t)ixc * C);
+      }
 #pragma unroll
-          for (int px = 0; px < PX; ++px) {
-            const int kx = col - px * S;   // compile-time after unrolling
-            if (kx >= 0 && kx < K) {
+      for (int col = 0; col < COLS; ++col) {
+        const int ix = ixb + col;
+        const float m = (rok && (unsigned)ix < (unsigned)W) ? 1.f : 0.f;
+        float v[CV];
+        dw_unpack<CV>(raw[col], v);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) acc[px][e] += v[e] * wr[kx][e];
-            }
+        for (int e = 0; e < CV; ++e) v[e] *= m;
+#pragma unroll
+        for (int px = 0; px < PX; ++px) {
+          const int kx = col - px * S;   // compile-time after unrolling
+          if (kx >= 0 && kx < K) {
+#pragma unroll
+            for (int e = 0; e < CV; ++e) acc[px][e] = fmaf(v[e], wr[kx][e], acc[px][e]);
           }
         }
       }
     }
-    float tot[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float tot[CV];
+#pragma unroll
+    for (int e = 0; e < CV; ++e) tot[e] = 0.f;
     bf16_t* yrow = y + ((size_t)((size_t)b * OH + oy) * OW) * C + c0;
 #pragma unroll
     for (int px = 0; px < PX; ++px) {
-      if (ox0 + px < OW) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[px][e] = apply_act(acc[px][e], act);
-        const uint4 u = pack8(acc[px]);
-        *reinterpret_cast<uint4*>(yrow + (size_t)(ox0 + px) * C) = u;
-        float r[8];
-        unpack8(u, r);  // the squeeze sees the stored (bf16-rounded) activations
+      for (int e = 0; e < CV; ++e) acc[px][e] = act1(acc[px][e], actp);
+      uint32_t pk[CV / 2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) tot[e] += r[e];
+      for (int i = 0; i < CV / 2; ++i) pk[i] = pack_bf2(acc[px][2 * i], acc[px][2 * i + 1]);
+      const bool ok = ox0 + px < OW;
+      if (ok) {
+        vec_t u;
+        uint32_t* uw = reinterpret_cast<uint32_t*>(&u);
+#pragma unroll
+        for (int i = 0; i < CV / 2; ++i) uw[i] = pk[i];
+        *reinterpret_cast<vec_t*>(yrow + (size_t)(ox0 + px) * C) = u;
+      }
+      const float m = ok ? 1.f : 0.f;   // the squeeze sees the stored (bf16-rounded) activations
+#pragma unroll
+      for (int i = 0; i < CV / 2; ++i) {
+        tot[2 * i] += m * bf2f(pk[i] & 0xffffu);
+        tot[2 * i + 1] += m * bf2f(pk[i] >> 16);
       }
     }
     if (sum_out) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) atomicAdd(&lsum[e * cgs + cg], tot[e]);
+      for (int e = 0; e < CV; ++e) atomicAdd(&lsum[e * cgs + cg], tot[e]);
     }
   }
   if (sum_out) {
     __syncthreads();
-    for (int c = tid; c < C; c += 256) atomicAdd(sum_out + (size_t)b * C + c, lsum[(c & 7) * cgs + (c >> 3)]);
+    for (int c = tid; c < C; c += 256) atomicAdd(sum_out + (size_t)b * C + c, lsum[(c % CV) * cgs + (c / CV)]);
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// Marching kernel (C % 4 == 0): a thread owns 4 channels x PX adjacent output columns and walks DOWN
+// a segment of output rows with a sliding window of K (+ S prefetched) input rows in registers (packed bf16),
+// so every input row is fetched ONCE per thread instead of once per filter row -- the strip kernel
+// above re-read each input row K times and the re-reads missed L2 (rocprofv3: FETCH_SIZE 3x the
+// input, TCC hit rate 37 %, SQ_WAIT_ANY 75 % of wave cycles on EfficientNet-B4's 95x95x192 layer).
+// The S rows of the NEXT output row are requested before the current row's FMAs (that is what the
+// S extra rows are for); the window slides by register moves.  Filter taps come from LDS ([tap][channel], one tile of 256 channels per
+// workgroup); the SE squeeze is accumulated per thread over its whole segment.
+// ---------------------------------------------------------------------------------------
+constexpr int dw_gcd(int a, int b) { return b == 0 ? a : dw_gcd(b, a % b); }
+
+template <int K, int S, int PX, int CV>
+__global__ void __launch_bounds__(256) dwconv_march_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, bf16_t* __restrict__ y,
+                                                           float* sum_out, int H, int W, int C, int pad_t, int pad_l,
+                                                           int OH, int OW, int act, int rows_per_seg, int nseg) {
+  static_assert(CV == 2 || CV == 4, "2 or 4 channels per thread");
+  typedef typename std::conditional<CV == 4, uint2, uint32_t>::type raw_t;
+  constexpr int COLS = (PX - 1) * S + K;
+  extern __shared__ float dw_lds[];
+  float* wl = dw_lds;                            // [K*K][256]
+  float* lsum = dw_lds + K * K * 256;            // [256]
+
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int cgs = C / CV;
+  const int CGB = min(cgs, 256 / CV);            // channel groups per workgroup (a tile of <= 256 channels)
+  const int SPB = 256 / CGB;                     // column strips x row segments per workgroup
+  const int ctiles = (cgs + CGB - 1) / CGB;
+  const int ct = blockIdx.x % ctiles;
+  const int sblk = blockIdx.x / ctiles;
+  const int cgl = tid % CGB, sl = tid / CGB;
+  const int cg = ct * CGB + cgl;
+  const int c0 = cg * CV;
+  const int sx = (OW + PX - 1) / PX;
+  const int item = sblk * SPB + sl;              // (segment, strip), strip fastest
+  const int strip = item % sx, seg = item / sx;
+  const bool live = sl < SPB && cg < cgs && seg < nseg;
+  const ActParams actp = make_act(act);
+
+  for (int i = tid; i < K * K * 256; i += 256) {
+    const int tap = i >> 8, c = i & 255;
+    const int ch = ct * CGB * CV + c;
+    wl[i] = (c < CGB * CV && ch < C) ? w[(size_t)tap * C + ch] : 0.f;
+  }
+  if (sum_out) lsum[tid] = 0.f;
+  __syncthreads();
+
+  float tot[CV];
+#pragma unroll
+  for (int e = 0; e < CV; ++e) tot[e] = 0.f;
+  if (live) {
+    const int ox0 = strip * PX;
+    const int oy_begin = seg * rows_per_seg;
+    const int oy_end = min(OH, oy_begin + rows_per_seg);
+    const int iy_start = oy_begin * S - pad_t;
+    const int ixb = ox0 * S - pad_l;
+    float bias4[CV];
+#pragma unroll
+    for (int e = 0; e < CV; ++e) bias4[e] = bias ? bias[c0 + e] : 0.f;
+    const bf16_t* ximg = x + (size_t)b * H * W * C + c0;
+    int xoff[COLS];          // clamped column offsets (elements)
+    float cmask[COLS];
+#pragma unroll
+    for (int col = 0; col < COLS; ++col) {
+      const int ix = ixb + col;
+      cmask[col] = (unsigned)ix < (unsigned)W ? 1.f : 0.f;
+      xoff[col] = min(max(ix, 0), W - 1) * C;
+    }
+    float win[K][COLS][CV];  // input rows of the current output row (fp32, zero outside the image)
+    raw_t nxt[S][COLS];      // the S rows the next output row adds, still packed (requested one row ahead)
+    float nmask[S];
+    auto load_row = [&](int j, raw_t* dst) __attribute__((always_inline)) -> float {   // input row iy_start + j
+      const int iy = iy_start + j;
+      const bool rok = (unsigned)iy < (unsigned)H;
+      const bf16_t* xrow = ximg + (size_t)(rok ? iy : 0) * W * C;
+#pragma unroll
+      for (int col = 0; col < COLS; ++col) dst[col] = *reinterpret_cast<const raw_t*>(xrow + xoff[col]);
+      return rok ? 1.f : 0.f;
+    };
+    auto unpack_row = [&](const raw_t* src, float rmask, float (*dst)[CV]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int col = 0; col < COLS; ++col) {
+        const uint32_t* u = reinterpret_cast<const uint32_t*>(&src[col]);
+        const float m = rmask * cmask[col];
+#pragma unroll
+        for (int i = 0; i < CV / 2; ++i) {
+          dst[col][2 * i] = m * bf2f(u[i] & 0xffffu);
+          dst[col][2 * i + 1] = m * bf2f(u[i] >> 16);
+        }
+      }
+    };
+    {
+      raw_t tmp[COLS];
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const float rm = load_row(j, tmp);
+        unpack_row(tmp, rm, win[j]);
+      }
+    }
+
+#pragma unroll 1
+    for (int t = 0; oy_begin + t < oy_end; ++t) {
+      const int oy = oy_begin + t;
+      asm volatile("" ::: "memory");   // filter taps stay in LDS: no hoisting of the K*K reads out of the loop
+      // request the S new rows of output row t + 1 before this row's FMAs
+#pragma unroll
+      for (int i = 0; i < S; ++i) nmask[i] = load_row((t + 1) * S + K - S + i, nxt[i]);
+      float acc[PX][CV];
+#pragma unroll
+      for (int px = 0; px < PX; ++px)
+#pragma unroll
+        for (int e = 0; e < CV; ++e) acc[px][e] = bias4[e];
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          float wv[CV];
+          if (CV == 4) {
+            const float4 w4 = *reinterpret_cast<const float4*>(&wl[(ky * K + kx) * 256 + cgl * 4]);
+            wv[0] = w4.x; wv[1] = w4.y; wv[CV - 2] = w4.z; wv[CV - 1] = w4.w;
+          } else {
+            const float2 w2 = *reinterpret_cast<const float2*>(&wl[(ky * K + kx) * 256 + cgl * 2]);
+            wv[0] = w2.x; wv[1] = w2.y;
+          }
+#pragma unroll
+          for (int px = 0; px < PX; ++px)
+#pragma unroll
+            for (int e = 0; e < CV; ++e) acc[px][e] = fmaf(win[ky][px * S + kx][e], wv[e], acc[px][e]);
+        }
+      }
+      bf16_t* yrow = y + ((size_t)((size_t)b * OH + oy) * OW) * C + c0;
+#pragma unroll
+      for (int px = 0; px < PX; ++px) {
+#pragma unroll
+        for (int e = 0; e < CV; ++e) acc[px][e] = act1(acc[px][e], actp);
+        uint32_t pk[CV / 2];
+#pragma unroll
+        for (int i = 0; i < CV / 2; ++i) pk[i] = pack_bf2(acc[px][2 * i], acc[px][2 * i + 1]);
+        const bool ok = ox0 + px < OW;
+        if (ok) {
+          raw_t u;
+          uint32_t* uw = reinterpret_cast<uint32_t*>(&u);
+#pragma unroll
+          for (int i = 0; i < CV / 2; ++i) uw[i] = pk[i];
+          *reinterpret_cast<raw_t*>(yrow + (size_t)(ox0 + px) * C) = u;
+        }
+        const float m = ok ? 1.f : 0.f;      // the squeeze sees the stored (bf16-rounded) activations
+#pragma unroll
+        for (int i = 0; i < CV / 2; ++i) {
+          tot[2 * i] += m * bf2f(pk[i] & 0xffffu);
+          tot[2 * i + 1] += m * bf2f(pk[i] >> 16);
+        }
+      }
+      // slide the window down by S rows (register moves), convert the prefetched rows into it
+#pragma unroll
+      for (int j = 0; j + S < K; ++j)
+#pragma unroll
+        for (int col = 0; col < COLS; ++col)
+#pragma unroll
+          for (int e = 0; e < CV; ++e) win[j][col][e] = win[j + S][col][e];
+#pragma unroll
+      for (int i = 0; i < S; ++i) unpack_row(nxt[i], nmask[i], win[K - S + i]);
+    }
+  }
+  if (sum_out) {
+    if (live) {
+#pragma unroll
+      for (int e = 0; e < CV; ++e) atomicAdd(&lsum[cgl * CV + e], tot[e]);
+    }
+    __syncthreads();
+    const int ch = ct * CGB * CV + tid;
+    if (tid < CGB * CV && ch < C) atomicAdd(sum_out + (size_t)b * C + ch, lsum[tid]);
+  }
+}
+
+template <int K, int S, int PX, int CV>
+static int launch_dwconv_march(const bf16_t* x, const float* w, const float* bias, bf16_t* y, float* sum_out, int B,
+                               int H, int W, int C, int pad_t, int pad_l, int OH, int OW, int act, hipStream_t st) {
+  const int cgs = C / CV;
+  const int CGB = cgs < 256 / CV ? cgs : 256 / CV, SPB = 256 / CGB;
+  const int ctiles = (cgs + CGB - 1) / CGB;
+  const int sx = (OW + PX - 1) / PX;
+  // split the rows into segments until the grid holds enough threads to fill the chip a few times over
+  const int64_t target = (int64_t)256 * 6 * 256;                     // threads wanted in flight
+  int nseg = 1;
+  while (nseg < OH / 8 && (int64_t)B * ctiles * CGB * sx * nseg < target) ++nseg;
+  const int rows_per_seg = (OH + nseg - 1) / nseg;
+  nseg = (OH + rows_per_seg - 1) / rows_per_seg;
+  const int sblks = (sx * nseg + SPB - 1) / SPB;
+  const size_t lds = ((size_t)K * K * 256 + 256) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)dwconv_march_kernel<K, S, PX, CV>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    attr_done = true;
+  }
+  TFIMM_LAUNCH((dwconv_march_kernel<K, S, PX, CV>), dim3((unsigned)(ctiles * sblks), (unsigned)B), dim3(256), lds, st,
+               x, w, bias, y, sum_out, H, W, C, pad_t, pad_l, OH, OW, act, rows_per_seg, nseg);
+  return 0;
 }
 
 template <int K, int S>
 static int launch_dwconv_strip(const bf16_t* x, const float* w, const float* bias, bf16_t* y, float* sum_out, int B,
                                int H, int W, int C, int pad_t, int pad_l, int OH, int OW, int act, hipStream_t st) {
   constexpr int PX = 4;
-  const int64_t items = (int64_t)OH * ((OW + PX - 1) / PX) * (C / 8);
+  // 4 channels per thread keep the accumulators + one filter row of weights under 64 VGPRs for the
+  // large filters (8 waves per SIMD to hide the load latency); 8 channels halve the instruction
+  // count where the filter is small
+  constexpr int CV = K >= 5 ? 4 : 8;
+  const int64_t items = (int64_t)OH * ((OW + PX - 1) / PX) * (C / CV);
   int64_t bpi = (items + 255) / 256;                    // blocks per image if every thread took one item
   const int64_t want = (8 * 256 + B - 1) / B;           // ~8 resident blocks per CU over the whole grid
   if (bpi > want) bpi = want < 1 ? 1 : want;
   const size_t lds = sum_out ? (size_t)C * sizeof(float) : 0;
-  TFIMM_LAUNCH((dwconv_strip_kernel<K, S, PX>), dim3((unsigned)bpi, (unsigned)B), dim3(256), lds, st, x, w, bias, y,
+  TFIMM_LAUNCH((dwconv_strip_kernel<K, S, PX, CV>), dim3((unsigned)bpi, (unsigned)B), dim3(256), lds, st, x, w, bias, y,
                sum_out, H, W, C, pad_t, pad_l, OH, OW, act);
   return 0;
 }
@@ -641,6 +888,21 @@ extern "C" int tfimm_hip_dwconv(const void* x, const float* w, const float* bias
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (C % 8 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0) &&
                    (((uintptr_t)w & 15) == 0);
+  const bool vec4 = (C % 4 == 0) && (((uintptr_t)x & 7) == 0) && (((uintptr_t)y & 7) == 0);
+  static int use_march = -1;
+  if (use_march < 0) {
+    const char* e = getenv("TFIMM_DW_NO_MARCH");
+    use_march = (e && e[0] == '1') ? 0 : 1;
+  }
+  if (use_march && vec4 && B <= 65535) {
+    const bf16_t* xb = (const bf16_t*)x;
+    bf16_t* yb = (bf16_t*)y;
+    if (k == 3 && stride == 1) return launch_dwconv_march<3, 1, 4, 4>(xb, w, bias, yb, sum_out, B, H, W, C, pad_t, pad_l, OH, OW, act, st);
+    if (k == 3 && stride == 2) return launch_dwconv_march<3, 2, 4, 4>(xb, w, bias, yb, sum_out, B, H, W, C, pad_t, pad_l, OH, OW, act, st);
+    if (k == 5 && stride == 1) return launch_dwconv_march<5, 1, 4, 2>(xb, w, bias, yb, sum_out, B, H, W, C, pad_t, pad_l, OH, OW, act, st);
+    if (k == 5 && stride == 2) return launch_dwconv_march<5, 2, 2, 2>(xb, w, bias, yb, sum_out, B, H, W, C, pad_t, pad_l, OH, OW, act, st);
+    // k = 7 (ConvNeXt): the 7-row fp32 window leaves one wave per SIMD and measures 2.5x slower than the strip kernel
+  }
   if (vec && C <= 8192 && B <= 65535) {
     const bf16_t* xb = (const bf16_t*)x;
     bf16_t* yb = (bf16_t*)y;
