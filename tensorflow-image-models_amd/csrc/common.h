@@ -81,13 +81,14 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 struct ActParams {
   float lo, hi, k, a, b, c;
   int cls;
+  int clamp;   // lo / hi are finite bounds (relu, relu6)
 };
 __device__ __forceinline__ ActParams make_act(int act) {
   ActParams q;
-  q.lo = -__builtin_inff(); q.hi = __builtin_inff(); q.k = 1.f; q.a = 0.f; q.b = 0.f; q.c = 0.f; q.cls = 0;
+  q.lo = -__builtin_inff(); q.hi = __builtin_inff(); q.k = 1.f; q.a = 0.f; q.b = 0.f; q.c = 0.f; q.cls = 0; q.clamp = 0;
   switch (act) {
-    case TFIMM_ACT_RELU: q.lo = 0.f; break;
-    case TFIMM_ACT_RELU6: q.lo = 0.f; q.hi = 6.f; break;
+    case TFIMM_ACT_RELU: q.lo = 0.f; q.clamp = 1; break;
+    case TFIMM_ACT_RELU6: q.lo = 0.f; q.hi = 6.f; q.clamp = 1; break;
     case TFIMM_ACT_SWISH: q.cls = 1; q.a = 1.f; break;
     case TFIMM_ACT_SIGMOID: q.cls = 1; q.b = 1.f; break;
     case TFIMM_ACT_TANH: q.cls = 1; q.k = 2.f; q.b = 2.f; q.c = -1.f; break;
@@ -110,10 +111,14 @@ __device__ __forceinline__ float gelu_erf(float v) {
 }
 __device__ __forceinline__ float act1(float v, const ActParams& q) {
   v = fminf(fmaxf(v, q.lo), q.hi);
+  // the empty asm statements keep hipcc from if-converting the (wave-uniform) class branches into
+  // selects, which would evaluate exp/rcp of BOTH classes for every element of every activation
   if (q.cls == 1) {
+    asm volatile("");
     const float sgm = __builtin_amdgcn_rcpf(1.f + __expf(-q.k * v));
     v = q.a * v * sgm + (q.b * sgm + q.c);
   } else if (q.cls == 2) {
+    asm volatile("");
     v = gelu_erf(v);
   }
   return v;
@@ -121,16 +126,62 @@ __device__ __forceinline__ float act1(float v, const ActParams& q) {
 __device__ __forceinline__ void act8(float* v, const ActParams& q) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(v[e], q.lo), q.hi);
-  if (q.cls == 1) {
+  if (q.cls == 1) {   // wave-uniform branches, kept as branches (see act1)
+    asm volatile("");
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float sgm = __builtin_amdgcn_rcpf(1.f + __expf(-q.k * v[e]));
       v[e] = q.a * v[e] * sgm + (q.b * sgm + q.c);
     }
   } else if (q.cls == 2) {
+    asm volatile("");
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
   }
+}
+
+// Same on four packed pairs (v_pk_* arithmetic, v_med3_f32 clamp); every class is a wave-uniform
+// branch, so an epilogue pays only for the activation it has.
+__device__ __forceinline__ void act8p(tfimm_f32x2* v, const ActParams& q) {
+  if (q.clamp) {
+    asm volatile("");
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e].x = __builtin_amdgcn_fmed3f(v[e].x, q.lo, q.hi);
+      v[e].y = __builtin_amdgcn_fmed3f(v[e].y, q.lo, q.hi);
+    }
+  } else if (q.cls == 1) {
+    asm volatile("");
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      tfimm_f32x2 sg;
+      sg.x = __builtin_amdgcn_rcpf(1.f + __expf(-q.k * v[e].x));
+      sg.y = __builtin_amdgcn_rcpf(1.f + __expf(-q.k * v[e].y));
+      v[e] = q.a * v[e] * sg + (q.b * sg + q.c);
+    }
+  } else if (q.cls == 2) {
+    asm volatile("");
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e].x = gelu_erf(v[e].x);
+      v[e].y = gelu_erf(v[e].y);
+    }
+  }
+}
+// eight bf16 (one 16-byte row segment) -> four fp32 pairs
+__device__ __forceinline__ void unpack8p(const uint4& u, tfimm_f32x2* f) {
+  f[0].x = __uint_as_float(u.x << 16); f[0].y = __uint_as_float(u.x & 0xffff0000u);
+  f[1].x = __uint_as_float(u.y << 16); f[1].y = __uint_as_float(u.y & 0xffff0000u);
+  f[2].x = __uint_as_float(u.z << 16); f[2].y = __uint_as_float(u.z & 0xffff0000u);
+  f[3].x = __uint_as_float(u.w << 16); f[3].y = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8p(const tfimm_f32x2* f) {
+  uint4 u;
+  u.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(f[0], tfimm_bf16x2));
+  u.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(f[1], tfimm_bf16x2));
+  u.z = __builtin_bit_cast(uint32_t, __builtin_convertvector(f[2], tfimm_bf16x2));
+  u.w = __builtin_bit_cast(uint32_t, __builtin_convertvector(f[3], tfimm_bf16x2));
+  return u;
 }
 
 // ---- wave64 reductions ---------------------------------------------------------------

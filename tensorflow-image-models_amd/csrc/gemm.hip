@@ -257,6 +257,12 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       ga.n_tiles = (int)ntiles;
       ga.cin64 = (kmode == K_CONV && (d.Cin % 64) == 0) ? 1 : 0;
       ga.cin_magic = ga.kw_magic = 0;
+      {
+        static const int dbg = getenv("TFIMM_GEMM_DBG") ? atoi(getenv("TFIMM_GEMM_DBG")) : 0;
+        ga.dbg = dbg;
+        static const char* dp = getenv("TFIMM_GEMM_DBG_PTR");
+        ga.dbg_ptr = dp ? (long long*)strtoull(dp, nullptr, 0) : nullptr;
+      }
       if (kmode == K_CONV && d.K < 65536) {
         if (d.Cin > 1) ga.cin_magic = (unsigned)(0x100000000ULL / (unsigned)d.Cin) + 1u;
         if (d.KW > 1) ga.kw_magic = (unsigned)(0x100000000ULL / (unsigned)d.KW) + 1u;

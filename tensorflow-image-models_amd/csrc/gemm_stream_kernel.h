@@ -42,6 +42,8 @@ struct GemmStreamArgs {
   int n_tiles;       // tiles_m * tiles_n
   int cin64;         // K_CONV: Cin % 64 == 0 (scalar tap stepping)
   unsigned cin_magic, kw_magic;   // K_CONV otherwise: floor(2^32 / d) + 1 for d = Cin, KW (0: K >= 65536, divide)
+  long long* dbg_ptr; // TFIMM_GEMM_DBG_PTR: s_memtime stamps of workgroup 0 (dbg & 64)
+  int dbg;           // TFIMM_GEMM_DBG: bit 64 = record the stamps (tools/gemm_stamps.py)
 };
 
 typedef void (*gemm_stream_fn)(const GemmStreamArgs);
@@ -232,6 +234,10 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   issue(0, 0);
   int cur = 0;
   bool stores_pending = false;   // the previous step ended an interior tile: its stores may still be in flight
+  int stamp_i = 0;
+  auto stamp = [&]() __attribute__((always_inline)) {
+    if ((pa.dbg & 64) && blockIdx.x == 0 && lane == 0 && stamp_i < 60) pa.dbg_ptr[wave * 64 + stamp_i++] = __builtin_readcyclecounter();
+  };
 
   for (int tile = t_first; tile < t_hi; tile += t_step) {
     const int mt = tile / p.tiles_n, nt = tile - mt * p.tiles_n;
@@ -240,37 +246,49 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
     const int e_n = n0 + wn * WTN + e_c8 * 8;        // first of this lane's 8 output channels
     const int e_m = m0 + wm * WTM + e_row;           // output row at (pass 0, iteration 0)
 
-    float bias8[8];
+    // VEC epilogue state of this tile.  A lane owns 8 consecutive channels (e_n ..) of the rows
+    // e_m + d, d = i * 32 + it * RPI (compile-time steps < 128).  Byte offsets of (row e_m, channel
+    // e_n) in the output / residual are computed once; a step adds the uniform d * ld and, where the
+    // row remap (patch rows -> token rows) or the residual period (pos_embed broadcast over images)
+    // wraps inside the tile, one uniform correction (host guarantees remap_in, res_mod are 0 or >= 128,
+    // so at most one wrap).  Rows >= M and channels >= N need no test: the descriptors end at the
+    // last valid element, so those lanes' offsets are out of range (loads 0, stores dropped).
+    tfimm_f32x2 bias2[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
-    if (VEC && p.bias) {
-      if (e_n + 7 < p.N) {
+    for (int e = 0; e < 4; ++e) bias2[e] = tfimm_f32x2{0.f, 0.f};
+    unsigned out_off0 = kOobOffset, res_off0 = kOobOffset;
+    int or0 = 0, rm0 = 0;
+    const int remap_eff = p.remap_in > 0 ? p.remap_in : 0x7fffffff;
+    const int resmod_eff = p.res_mod > 0 ? p.res_mod : 0x7fffffff;
+    const unsigned ldc2 = (unsigned)p.ldc * 2u, ldr2 = (unsigned)p.ldr * 2u;
+    const unsigned out_wrap = p.remap_in > 0 ? (unsigned)(p.remap_out - p.remap_in) * ldc2 : 0u;
+    const unsigned res_wrap = p.res_mod > 0 ? (unsigned)p.res_mod * ldr2 : 0u;
+    if (VEC) {
+      const bool col_ok = e_n < p.N;   // N % 8 == 0: all 8 channels or none
+      if (p.bias && col_ok) {
         const float4 b0 = *reinterpret_cast<const float4*>(p.bias + e_n);
         const float4 b1 = *reinterpret_cast<const float4*>(p.bias + e_n + 4);
-        bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
-        bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+        bias2[0] = tfimm_f32x2{b0.x, b0.y}; bias2[1] = tfimm_f32x2{b0.z, b0.w};
+        bias2[2] = tfimm_f32x2{b1.x, b1.y}; bias2[3] = tfimm_f32x2{b1.z, b1.w};
+      }
+      const int em = e_m < p.M ? e_m : p.M;          // clamp: offsets stay inside 32 bits
+      rm0 = p.res_mod > 0 ? em % p.res_mod : em;
+      const int oq0 = p.remap_in > 0 ? em / p.remap_in : 0;
+      or0 = p.remap_in > 0 ? em - oq0 * p.remap_in : em;
+      const int om0 = p.remap_in > 0 ? oq0 * p.remap_out + or0 + p.remap_off : em;
+      if (col_ok) {
+        out_off0 = (unsigned)(((size_t)om0 * p.ldc + e_n) * 2);
+        res_off0 = (unsigned)(((size_t)rm0 * p.ldr + e_n) * 2);
       }
     }
-
-    // VEC: rows advance by compile-time steps d = i * 32 + it * RPI < 128 from e_m, so the modulo of
-    // res_mod (residual broadcast over images, e.g. pos_embed) and the div/mod of the row remap
-    // (patch rows -> token rows) are done ONCE per tile and stepped with one conditional wrap each
-    // (host guarantees res_mod, remap_in are 0 or >= 128 for this flavour).
-    const int resmod_eff = p.res_mod > 0 ? p.res_mod : 0x7fffffff;
-    const int remap_eff = p.remap_in > 0 ? p.remap_in : 0x7fffffff;
-    const int rm0 = p.res_mod > 0 ? e_m % p.res_mod : e_m;
-    const int oq0 = p.remap_in > 0 ? e_m / p.remap_in : 0;
-    const int or0 = p.remap_in > 0 ? e_m - oq0 * p.remap_in : e_m;
-    const int ooff = p.remap_in > 0 ? p.remap_off : 0;
-    // residual row of (pass i, iteration it).  Issued unconditionally: without a residual the
-    // descriptor has zero records and every lane reads 0 -- no branch, so hipcc's vmcnt
+    // residual segment of (pass i, iteration it).  Issued unconditionally: without a residual the
+    // descriptor has zero records and every lane reads 0 -- no VMEM inside a branch, so hipcc's vmcnt
     // bookkeeping through the epilogue stays exact.
     uint4 rres[ITS];
     auto load_res1 = [&](int i, int it) __attribute__((always_inline)) {
       const int d = i * 32 + it * RPI;
-      int rm = rm0 + d;
-      rm -= rm >= resmod_eff ? resmod_eff : 0;
-      const unsigned off = (e_m + d < p.M && e_n < p.N) ? (unsigned)(((size_t)rm * p.ldr + e_n) * 2) : kOobOffset;
+      unsigned off = res_off0 + (unsigned)d * ldr2;
+      off -= (rm0 + d >= resmod_eff) ? res_wrap : 0u;
       rres[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, (int)off, 0, 0));
     };
 
@@ -330,8 +348,10 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
       cur ^= 1;
     };
 
+    stamp();
     for (int kt = 0; kt + 1 < nk; ++kt) kstep(false);
     kstep(true);
+    stamp();
 
     // ---- epilogue (per wave).  Aliased staging lives in the stage consumed last (index cur^1 now):
     //      wait until every wave is done reading it; the next refill of that stage is issued only
@@ -369,33 +389,43 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
           const unsigned addr = (unsigned)(size_t)(lds_ptr_t)(&sEw[frow * WTN + epi_slot(frow, slot) * 4]);
           asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
         }
+      if (i == 0) stamp();
       if (VEC) {
         // read back row-contiguous: lane handles 8 consecutive channels of one row
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
           const int pr = it * RPI + e_row;
-          const int m = e_m + i * 32 + it * RPI;
           const float4 lo = *reinterpret_cast<const float4*>(&sEw[pr * WTN + epi_slot(pr, 2 * e_c8) * 4]);
           const float4 hi = *reinterpret_cast<const float4*>(&sEw[pr * WTN + epi_slot(pr, 2 * e_c8 + 1) * 4]);
-          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          tfimm_f32x2 v[4] = {{lo.x, lo.y}, {lo.z, lo.w}, {hi.x, hi.y}, {hi.z, hi.w}};
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += bias8[e];
-          float r8[8];
-          unpack8(rres[it], r8);
-          // the next pass's row for this slot: requested before this iteration's store and consumed
+          for (int e = 0; e < 4; ++e) v[e] += bias2[e];
+          const uint4 rraw = rres[it];
+          // the next pass's segment for this slot: requested before this iteration's store and consumed
           // a pass later, so its return never sits behind a store acknowledgement
           if (i + 1 < TM) load_res1(i + 1, it);
+          // wave-uniform branches around pure VALU work (the empty asm keeps them branches)
+          tfimm_f32x2 r2[4];
+          if (has_res) {
+            asm volatile("");
+            unpack8p(rraw, r2);
+            if (p.act_after_res) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += p.act_after_res ? r8[e] : 0.f;
-          act8(v, actp);
+              for (int e = 0; e < 4; ++e) v[e] += r2[e];
+            }
+          }
+          act8p(v, actp);
+          if (has_res && !p.act_after_res) {
+            asm volatile("");
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += p.act_after_res ? 0.f : r8[e];
+            for (int e = 0; e < 4; ++e) v[e] += r2[e];
+          }
           const int d = i * 32 + it * RPI;
-          int orr = or0 + d, oq = oq0;
-          if (orr >= remap_eff) { orr -= remap_eff; ++oq; }
-          const int om = oq * p.remap_out + orr + ooff;
-          const unsigned off = (m < p.M && e_n < p.N) ? (unsigned)(((size_t)om * p.ldc + e_n) * 2) : kOobOffset;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pack8(v)), rsrc_o, (int)off, 0, 0);
+          unsigned off = out_off0 + (unsigned)d * ldc2;
+          off += (or0 + d >= remap_eff) ? out_wrap : 0u;
+          // (default cache policy: non-temporal stores are 3-8 % faster for this launch alone but the
+          // next layer then misses L2/MALL on what it reads first -- ResNet-50 end to end -1.5 %)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pack8p(v)), rsrc_o, (int)off, 0, 0);
         }
       } else {
         // catch-all: element loop over the staged block (the wave's own LDS, in order -> no barrier)
@@ -419,6 +449,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
           }
         }
       }
+      stamp();
     }
     stores_pending = VEC && interior;
   }

@@ -235,6 +235,14 @@ CASES["pair_conv1ch_8x8_patch"] = lambda: _conv_case(2, 32, 32, 1, 8, 8, 8, 0, b
 for _t in (21, 24):
     CASES[f"conv3x3_stream_multiround_tile{_t:02d}"] = (
         lambda t=_t: _conv_case(32, 56, 56, 64, 64, 3, 1, 1, act="relu", residual=True, seed=70 + t, tile=t))
+# 256x256 persistent tile: deep K (many k-tiles per tile, several tiles per workgroup), K tail, two k-tiles
+CASES["gemm_t21_deepk_3000x1600x520"] = lambda: _gemm_case(3000, 1600, 520, act="gelu", residual=True, tile=21, seed=91)
+CASES["gemm_t21_two_ktiles_70000x128x512"] = lambda: _gemm_case(70000, 128, 512, tile=21, seed=92)
+CASES["gemm_t21_ktail_5000x200x256"] = lambda: _gemm_case(5000, 200, 256, act="relu", tile=21, seed=93)
+CASES["gemm_t21_resmod_remap_19600x192x768"] = lambda: _gemm_case(19600, 192, 768, residual=True, res_mod=196,
+                                                                 remap=(196, 197, 1), tile=21, seed=96)
+CASES["conv3x3_t21_cin128_multiround"] = lambda: _conv_case(24, 28, 28, 128, 256, 3, 1, 1, act="relu", residual=True, seed=94, tile=21)
+CASES["conv3x3_t21_cin40_s2"] = lambda: _conv_case(16, 31, 29, 40, 264, 3, 2, 1, act="relu", seed=95, tile=21)
 CASES["conv3x3_cin128_tapstep"] = lambda: _conv_case(4, 14, 14, 128, 96, 3, 1, 1, act="relu", seed=75)
 CASES["conv3x3_s2_cin192_tapstep"] = lambda: _conv_case(3, 15, 15, 192, 64, 3, 2, 1, seed=76)
 CASES["conv1x1_s2_cin64_stream"] = lambda: _conv_case(2, 28, 28, 64, 128, 1, 2, 0, seed=77, tile=23)
