@@ -177,6 +177,50 @@ typedef struct tfimm_attn_desc {
 TFIMM_API int tfimm_hip_attention(const tfimm_attn_desc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * tfimm_hip_talking_heads_attention: CaiT self-attention with the two head-mixing Dense layers
+ * around the softmax (TalkingHeadAttention.call, cait.py:233-262):
+ *     s[b,h,i,j]  = scale * q[b,i,h,:] . k[b,j,h,:]
+ *     a[b,h',i,j] = softmax_j( sum_h s[b,h,i,j] * proj_l_w[h][h'] + proj_l_b[h'] )
+ *     w[b,g,i,j]  = sum_h' a[b,h',i,j] * proj_w_w[h'][g] + proj_w_b[g]
+ *     out[b,i,g,:] = sum_j w[b,g,i,j] * v[b,j,g,:]
+ * qkv packed as for tfimm_hip_attention (bf16 [rows][3*heads*hd], rows = batch * n_tokens);
+ * proj_*_w are the Keras kernels [heads_in][heads_out] in fp32.  MFMA kernel for hd in {32, 48} (every
+ * CaiT configuration has hd = 48) and heads in {1, 2, 3, 4, 6, 8, 16}; any other shape takes a plain
+ * fp32 kernel (one workgroup per query row) as long as 2 * heads * n_tokens floats fit in LDS.
+ * ------------------------------------------------------------------------------------- */
+typedef struct tfimm_tha_desc {
+  const void* qkv;
+  void* out;                /* bf16 [rows][heads*hd] */
+  const float* proj_l_w;    /* fp32 [heads][heads] */
+  const float* proj_l_b;    /* fp32 [heads] */
+  const float* proj_w_w;
+  const float* proj_w_b;
+  int32_t batch, n_tokens, heads, hd;
+  float scale;
+} tfimm_tha_desc;
+
+TFIMM_API int tfimm_hip_talking_heads_attention(const tfimm_tha_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * tfimm_hip_class_attention: the class token of every image attends to all of its tokens
+ * (ClassAttention.call, cait.py:118-146 between the q/k/v and proj layers):
+ *     out[b, h*hd + d] = sum_j softmax_j( q[b, h, :] . k[b, j, h, :] ) * v[b, j, h, d]
+ * q: bf16, one row per image with row stride ldq (ALREADY scaled: the caller folds
+ * (D/H)^-0.5 into the q layer); kv: bf16 [B*n_tokens][ldkv] holding k in columns
+ * [0, heads*hd) and v in [heads*hd, 2*heads*hd); out: bf16, one row per image, stride ldo.
+ * ------------------------------------------------------------------------------------- */
+TFIMM_API int tfimm_hip_class_attention(const void* q, const void* kv, void* out, int B, int n_tokens, int heads,
+                              int hd, int ldq, int ldkv, int ldo, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * tfimm_hip_copy_rows: dst[b][dst_row0 + r][:] = src[b][r][:] for r < src_rows -- one input of
+ * a tf.concat along the token axis (cait.py:425-426: class token in front of the patch tokens).
+ * bf16 rows of d elements (16-byte vectors when d % 8 == 0 and both buffers are 16-byte aligned).
+ * ------------------------------------------------------------------------------------- */
+TFIMM_API int tfimm_hip_copy_rows(const void* src, void* dst, int B, int src_rows, int dst_rows, int dst_row0,
+                        int d, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * tfimm_hip_maxpool: k x k / stride max pool with symmetric zero padding `pad`, NHWC bf16.
  * Padding contributes ZEROS (the reference pads with ZeroPadding2D and pools VALID,
  * resnet.py:538-540), not -inf.

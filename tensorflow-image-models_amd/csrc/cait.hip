@@ -1,0 +1,460 @@
+// CaiT attention operators (gfx950): talking-heads attention, class attention, token-axis concat.
+// See include/tfimm_hip.h for the reference call sites (tfimm/architectures/cait.py).
+//
+// tfimm_hip_talking_heads_attention
+// ---------------------------------
+//   attn = softmax_j( proj_l( scale * q k^T ) );  out = proj_w(attn) v      (cait.py:239-256)
+// proj_l / proj_w are Dense(H -> H) layers over the HEAD axis, applied at every (query, key)
+// position, so the H score maps of one position must meet before the softmax and again before the
+// P.V product.  The kernel keeps them together in registers:
+//   * one workgroup = 4 waves = 64 query rows of one image, ALL heads; a wave owns 16 queries and
+//     walks the keys in tiles of 16.  For a tile it computes S_h^T = K_h . Q_h^T for every head h
+//     (v_mfma_f32_16x16x32_bf16, K as the "a" operand): a lane then holds, for its query (lane & 15)
+//     and its 4 keys (4 * (lane >> 4) + r), the scores of all H heads in H x 4 registers -- the
+//     head mixing is H x H scalar-weight FMAs per register, weights in SGPRs.
+//   * the softmax runs over MIXED logits, so a one-pass online softmax would need the P.V partial
+//     sums of every (mixed head, value head) pair.  Instead the keys are walked twice: pass 1
+//     gathers max / sum of every (mixed head, query) (QK^T + first mixing only), pass 2 recomputes
+//     the logits, normalises, applies the second mixing and multiplies with V.  QK^T is cheap next
+//     to the mixing (H^2 VALU FMAs per position against 2 * hd MFMA MACs).
+//   * P (accumulator layout: query = lane & 15, keys 4g .. 4g+3) is exactly the "b" operand of
+//     v_mfma_f32_16x16x16_bf16, with V^T (staged transposed in LDS) as "a": O^T = V^T . P^T needs
+//     no shuffle.  Output accumulators are 4 * hd/16 registers per value head, so value heads are
+//     processed in groups of <= 8 (H = 16: pass 2 runs twice).
+//   * K block [32 keys][D] and V^T block [D][32 keys] of the image are staged per workgroup; the
+//     workgroup's Q rows live in LDS when they fit, else Q fragments come from L1/L2.
+#include "common.h"
+
+#include <cstdlib>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+
+struct ThaArgs {
+  const bf16_t* qkv;
+  bf16_t* out;
+  const float* wl; const float* bl;   // proj_l kernel [H_in][H_out], bias [H]
+  const float* ww; const float* bw;   // proj_w
+  int batch, n, heads;
+  float scale;
+  int ld, dmodel;
+  int qchunks;
+  int kstr;       // LDS row stride (elements) of the K / Q blocks
+  int q_in_lds;
+};
+
+constexpr int THA_KB = 32;        // keys staged per step
+constexpr int THA_VSTR = THA_KB + 8;
+
+template <int H, int HG, int DT>
+__global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p) {
+  constexpr int HD = DT * 16;
+  constexpr int KS = (HD + 31) / 32;
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) char smem_tha[];
+  const int D = p.dmodel;
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_tha);                     // [THA_KB][kstr]
+  bf16_t* Vt = Ks + THA_KB * p.kstr;                                     // [D][THA_VSTR]
+  float* St = reinterpret_cast<float*>(Vt + (size_t)D * THA_VSTR);       // [4 waves][H][16][2]
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(St + 4 * H * 16 * 2);           // [64][kstr] (q_in_lds)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int qc = blockIdx.x % p.qchunks;
+  const int img = blockIdx.x / p.qchunks;
+  const int64_t row0 = (int64_t)img * p.n;
+  const int q = qc * 64 + wave * 16 + l15;
+  const bool q_ok = q < p.n;
+  const int CH = D / 8;             // 16-byte chunks per token row of one of q / k / v
+
+  if (p.q_in_lds) {
+    for (int id = tid; id < 64 * CH; id += 256) {
+      const int r = id / CH, c = id - r * CH;
+      const int t = qc * 64 + r;
+      uint4 u = make_uint4(0u, 0u, 0u, 0u);
+      if (t < p.n) u = *reinterpret_cast<const uint4*>(p.qkv + (row0 + t) * p.ld + c * 8);
+      *reinterpret_cast<uint4*>(&Qs[r * p.kstr + c * 8]) = u;
+    }
+  }
+  // Q fragment of head h, k-step ks for this lane's query: d = ks*32 + g*8 .. +8 (zero beyond HD)
+  auto q_frag = [&](int h, int ks) -> bf16x8 {
+    const int d0 = ks * 32 + g * 8;
+    uint4 u = make_uint4(0u, 0u, 0u, 0u);
+    if (d0 < HD) {
+      if (p.q_in_lds) u = *reinterpret_cast<const uint4*>(&Qs[(wave * 16 + l15) * p.kstr + h * HD + d0]);
+      else if (q_ok) u = *reinterpret_cast<const uint4*>(p.qkv + (row0 + q) * p.ld + h * HD + d0);
+    }
+    return __builtin_bit_cast(bf16x8, u);
+  };
+
+  auto stage = [&](int kb, bool with_v) {
+    __syncthreads();   // previous block fully consumed (and Qs written, first time)
+    for (int id = tid; id < THA_KB * CH; id += 256) {
+      const int key = id / CH, c = id - key * CH;
+      const int t = kb + key;
+      uint4 ku = make_uint4(0u, 0u, 0u, 0u), vu = make_uint4(0u, 0u, 0u, 0u);
+      if (t < p.n) {
+        const bf16_t* kp = p.qkv + (row0 + t) * p.ld + D + c * 8;
+        ku = *reinterpret_cast<const uint4*>(kp);
+        if (with_v) vu = *reinterpret_cast<const uint4*>(kp + D);
+      }
+      *reinterpret_cast<uint4*>(&Ks[key * p.kstr + c * 8]) = ku;
+      if (with_v) {
+        const uint32_t vw[4] = {vu.x, vu.y, vu.z, vu.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          Vt[(c * 8 + e) * THA_VSTR + key] = (bf16_t)((vw[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+      }
+    }
+    __syncthreads();
+  };
+
+  // mixed logits (log2 units) of key tile t of the staged block, all H mixed heads
+  const float cs = p.scale * LOG2E;
+  auto logits = [&](int kb, int t, f32x4* mixed) __attribute__((always_inline)) {
+#pragma unroll
+    for (int hp = 0; hp < H; ++hp) {
+      const float b = p.bl[hp] * LOG2E;
+      mixed[hp] = (f32x4){b, b, b, b};
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int d0 = ks * 32 + g * 8;
+        uint4 ku = make_uint4(0u, 0u, 0u, 0u);
+        if (d0 < HD) ku = *reinterpret_cast<const uint4*>(&Ks[(t * 16 + l15) * p.kstr + h * HD + d0]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ku), q_frag(h, ks), acc, 0, 0, 0);
+      }
+      acc *= cs;
+#pragma unroll
+      for (int hp = 0; hp < H; ++hp) mixed[hp] += p.wl[h * H + hp] * acc;
+    }
+    if (kb + THA_KB > p.n) {   // last block: keys beyond the sequence take no part in the softmax
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (kb + t * 16 + g * 4 + r >= p.n) {
+#pragma unroll
+          for (int hp = 0; hp < H; ++hp) mixed[hp][r] = -1e30f;
+        }
+    }
+  };
+
+  // ---- pass 1: max / sum of every (mixed head, query), over this lane's keys first
+  {
+    float m_run[H], l_run[H];
+#pragma unroll
+    for (int hp = 0; hp < H; ++hp) { m_run[hp] = -1e30f; l_run[hp] = 0.f; }
+    for (int kb = 0; kb < p.n; kb += THA_KB) {
+      stage(kb, false);
+#pragma unroll
+      for (int t = 0; t < THA_KB / 16; ++t) {
+        f32x4 mixed[H];
+        logits(kb, t, mixed);
+#pragma unroll
+        for (int hp = 0; hp < H; ++hp) {
+          const f32x4 v = mixed[hp];
+          const float m_new = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), m_run[hp]);
+          l_run[hp] = l_run[hp] * __builtin_amdgcn_exp2f(m_run[hp] - m_new) + __builtin_amdgcn_exp2f(v[0] - m_new) + __builtin_amdgcn_exp2f(v[1] - m_new) +
+                      __builtin_amdgcn_exp2f(v[2] - m_new) + __builtin_amdgcn_exp2f(v[3] - m_new);
+          m_run[hp] = m_new;
+        }
+      }
+    }
+    // combine the four key groups (g) of a query, publish (max, 1 / sum)
+#pragma unroll
+    for (int hp = 0; hp < H; ++hp) {
+      float m = fmaxf(m_run[hp], __shfl_xor(m_run[hp], 16, 64));
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float l = l_run[hp] * __builtin_amdgcn_exp2f(m_run[hp] - m);
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      if (g == 0) {
+        St[((wave * H + hp) * 16 + l15) * 2 + 0] = m;
+        St[((wave * H + hp) * 16 + l15) * 2 + 1] = 1.f / l;
+      }
+    }
+  }
+
+  // ---- pass 2: probabilities, second mixing, P.V -- value heads in groups of HG
+  for (int hq0 = 0; hq0 < H; hq0 += HG) {
+    f32x4 o[HG][DT];
+#pragma unroll
+    for (int i = 0; i < HG; ++i)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[i][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < p.n; kb += THA_KB) {
+      stage(kb, true);
+#pragma unroll
+      for (int t = 0; t < THA_KB / 16; ++t) {
+        f32x4 pr[H];
+        logits(kb, t, pr);
+#pragma unroll
+        for (int hp = 0; hp < H; ++hp) {
+          const float m = St[((wave * H + hp) * 16 + l15) * 2 + 0];
+          const float il = St[((wave * H + hp) * 16 + l15) * 2 + 1];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pr[hp][r] = __builtin_amdgcn_exp2f(pr[hp][r] - m) * il;
+        }
+#pragma unroll
+        for (int i = 0; i < HG; ++i) {
+          const int hq = hq0 + i;
+          const float b = p.bw[hq];
+          f32x4 a = {b, b, b, b};
+#pragma unroll
+          for (int hp = 0; hp < H; ++hp) a += p.ww[hp * H + hq] * pr[hp];
+          // keys beyond the sequence carry the bias b, but their V rows are staged as zeros
+          const uint2 pu = make_uint2(pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]));
+          const bf16x4_t pf = __builtin_bit_cast(bf16x4_t, pu);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const uint2 vu = *reinterpret_cast<const uint2*>(&Vt[(hq * HD + dt * 16 + l15) * THA_VSTR + t * 16 + g * 4]);
+            o[i][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16x4_t, vu), pf, o[i][dt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // lane (q, g) holds d = dt*16 + g*4 + r of each value head
+    if (q_ok) {
+      bf16_t* op = p.out + (row0 + q) * D;
+#pragma unroll
+      for (int i = 0; i < HG; ++i)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const f32x4 v = o[i][dt];
+          *reinterpret_cast<uint2*>(op + (hq0 + i) * HD + dt * 16 + g * 4) =
+              make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        }
+    }
+  }
+}
+
+template <int H, int HG, int DT>
+int launch_tha(const ThaArgs& a, size_t lds, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)tha_kernel<H, HG, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  const int64_t nblocks = (int64_t)a.batch * a.qchunks;
+  if (nblocks > 0x7fffffffLL) TFIMM_FAIL(TFIMM_EINVAL, "talking_heads_attention: grid too large");
+  TFIMM_LAUNCH((tha_kernel<H, HG, DT>), dim3((unsigned)nblocks), dim3(256), lds, st, a);
+  return 0;
+}
+
+template <int DT>
+int launch_tha_heads(const ThaArgs& a, size_t lds, hipStream_t st) {
+  switch (a.heads) {
+    case 1: return launch_tha<1, 1, DT>(a, lds, st);
+    case 2: return launch_tha<2, 2, DT>(a, lds, st);
+    case 3: return launch_tha<3, 3, DT>(a, lds, st);
+    case 4: return launch_tha<4, 4, DT>(a, lds, st);
+    case 6: return launch_tha<6, 6, DT>(a, lds, st);
+    case 8: return launch_tha<8, 8, DT>(a, lds, st);
+    case 16: return launch_tha<16, 8, DT>(a, lds, st);
+    default: TFIMM_FAIL(TFIMM_EUNSUP, "talking_heads_attention: %d heads not built (1, 2, 3, 4, 6, 8, 16)", a.heads);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Catch-all talking-heads attention (any head dim / head count, unaligned rows): one workgroup per
+// query row, the H x N score / probability maps of that row in LDS, plain fp32 loops.  Serves the
+// reference's miniature test configuration (embed_dim 4, 2 heads); every published CaiT takes the
+// MFMA kernel above.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) tha_generic_kernel(const ThaArgs p, int hd) {
+  extern __shared__ float tg[];
+  const int H = p.heads, N = p.n;
+  float* s0 = tg;                 // [H][N] scores, later mixed probabilities
+  float* s1 = tg + (size_t)H * N; // [H][N] mixed logits / probabilities
+  const int tid = threadIdx.x;
+  const int img = blockIdx.x / N, i = blockIdx.x - img * N;
+  const int64_t row0 = (int64_t)img * N;
+  const bf16_t* qrow = p.qkv + (row0 + i) * p.ld;
+  for (int id = tid; id < H * N; id += 256) {
+    const int h = id / N, j = id - h * N;
+    const bf16_t* krow = p.qkv + (row0 + j) * p.ld + p.dmodel + h * hd;
+    float acc = 0.f;
+    for (int d = 0; d < hd; ++d) acc += (p.scale * bf2f(qrow[h * hd + d])) * bf2f(krow[d]);
+    s0[id] = acc;
+  }
+  __syncthreads();
+  for (int id = tid; id < H * N; id += 256) {
+    const int hp = id / N, j = id - hp * N;
+    float acc = p.bl[hp];
+    for (int h = 0; h < H; ++h) acc += s0[h * N + j] * p.wl[h * H + hp];
+    s1[id] = acc;
+  }
+  __syncthreads();
+  // softmax over j, one wave per mixed head
+  for (int hp = tid >> 6; hp < H; hp += 4) {
+    const int lane = tid & 63;
+    float m = -1e30f;
+    for (int j = lane; j < N; j += 64) m = fmaxf(m, s1[hp * N + j]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int j = lane; j < N; j += 64) {
+      const float e = __expf(s1[hp * N + j] - m);
+      s1[hp * N + j] = e;
+      sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int j = lane; j < N; j += 64) s1[hp * N + j] *= inv;
+  }
+  __syncthreads();
+  for (int id = tid; id < H * N; id += 256) {
+    const int hq = id / N, j = id - hq * N;
+    float acc = p.bw[hq];
+    for (int hp = 0; hp < H; ++hp) acc += s1[hp * N + j] * p.ww[hp * H + hq];
+    s0[id] = acc;
+  }
+  __syncthreads();
+  for (int id = tid; id < p.dmodel; id += 256) {
+    const int hq = id / hd;
+    const bf16_t* vcol = p.qkv + row0 * p.ld + 2 * p.dmodel + id;
+    float acc = 0.f;
+    for (int j = 0; j < N; ++j) acc += s0[hq * N + j] * bf2f(vcol[(int64_t)j * p.ld]);
+    p.out[(row0 + i) * p.dmodel + id] = (bf16_t)f2bf(acc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Class attention: ONE query (the class token) per (image, head) against all tokens.
+// One wave per (image, head): scores into LDS (lane = key), softmax by wave reductions, then
+// lane = channel for the weighted sum of V.  q is already scaled (host folds scale into the q layer).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) class_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ kv,
+                                                        bf16_t* __restrict__ out, int n, int heads, int hd, int ldq,
+                                                        int ldkv, int ldo) {
+  extern __shared__ float cls_s[];   // [n] scores, then probabilities
+  const int lane = threadIdx.x;
+  const int h = blockIdx.x % heads;
+  const int img = blockIdx.x / heads;
+  const int dmodel = heads * hd;
+  const bf16_t* qp = q + (int64_t)img * ldq + h * hd;
+  const bf16_t* kbase = kv + (int64_t)img * n * ldkv + h * hd;
+  float mx = -1e30f;
+  for (int j = lane; j < n; j += 64) {
+    const bf16_t* kp = kbase + (int64_t)j * ldkv;
+    float s = 0.f;
+    for (int d = 0; d < hd; ++d) s += bf2f(qp[d]) * bf2f(kp[d]);
+    cls_s[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < n; j += 64) {
+    const float e = __expf(cls_s[j] - mx);
+    cls_s[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __syncthreads();
+  const float inv = 1.f / sum;
+  for (int d = lane; d < hd; d += 64) {
+    const bf16_t* vp = kbase + dmodel + d;
+    float acc = 0.f;
+    for (int j = 0; j < n; ++j) acc += cls_s[j] * bf2f(vp[(int64_t)j * ldkv]);
+    out[(int64_t)img * ldo + h * hd + d] = (bf16_t)f2bf(acc * inv);
+  }
+}
+
+__global__ void copy_rows_scalar_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int64_t total,
+                                        int src_rows, int dst_rows, int dst_row0, int d) {
+  const int64_t per_img = (int64_t)src_rows * d;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / per_img;
+    dst[(b * dst_rows + dst_row0) * d + (i - b * per_img)] = src[i];
+  }
+}
+
+// dst[b][dst_row0 + r][:] = src[b][r][:], 16-byte vectors
+__global__ void copy_rows_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t total, int src_rows,
+                                 int dst_rows, int dst_row0, int d8) {
+  const int64_t per_img = (int64_t)src_rows * d8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / per_img;
+    const int64_t r = i - b * per_img;
+    dst[(b * dst_rows + dst_row0) * d8 + r] = src[i];
+  }
+}
+
+}  // namespace
+
+extern "C" int tfimm_hip_talking_heads_attention(const tfimm_tha_desc* dp, void* stream) {
+  if (!dp) TFIMM_FAIL(TFIMM_EINVAL, "talking_heads_attention: null descriptor");
+  const tfimm_tha_desc& d = *dp;
+  if (!d.qkv || !d.out || !d.proj_l_w || !d.proj_l_b || !d.proj_w_w || !d.proj_w_b)
+    TFIMM_FAIL(TFIMM_EINVAL, "talking_heads_attention: null pointer");
+  if (d.batch <= 0 || d.n_tokens <= 0 || d.heads <= 0 || d.hd <= 0)
+    TFIMM_FAIL(TFIMM_EINVAL, "talking_heads_attention: bad shape");
+  ThaArgs a;
+  a.qkv = (const bf16_t*)d.qkv; a.out = (bf16_t*)d.out;
+  a.wl = d.proj_l_w; a.bl = d.proj_l_b; a.ww = d.proj_w_w; a.bw = d.proj_w_b;
+  a.batch = d.batch; a.n = d.n_tokens; a.heads = d.heads; a.scale = d.scale;
+  a.dmodel = d.heads * d.hd; a.ld = 3 * a.dmodel;
+  a.qchunks = (d.n_tokens + 63) / 64;
+  a.kstr = 0; a.q_in_lds = 0;
+  hipStream_t st = (hipStream_t)stream;
+  const bool heads_built = d.heads <= 4 || d.heads == 6 || d.heads == 8 || d.heads == 16;
+  if ((d.hd != 32 && d.hd != 48) || !heads_built || ((uintptr_t)d.qkv & 15) || ((uintptr_t)d.out & 7)) {
+    const size_t lds = (size_t)2 * d.heads * d.n_tokens * 4;
+    if (lds > 160 * 1024) TFIMM_FAIL(TFIMM_EUNSUP, "talking_heads_attention: hd=%d heads=%d n=%d has no kernel", d.hd, d.heads, d.n_tokens);
+    static bool attr_done = false;
+    if (!attr_done) {
+      TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)tha_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_done = true;
+    }
+    const int64_t nb = (int64_t)d.batch * d.n_tokens;
+    if (nb > 0x7fffffffLL) TFIMM_FAIL(TFIMM_EINVAL, "talking_heads_attention: grid too large");
+    TFIMM_LAUNCH(tha_generic_kernel, dim3((unsigned)nb), dim3(256), lds, st, a, d.hd);
+    return 0;
+  }
+  // row stride of the K / Q blocks: >= D + 8 and == 72 (mod 128) elements, i.e. 36 dwords (mod 64 banks):
+  // the 16-row ds_read_b128 fragment reads are then conflict free
+  a.kstr = ((a.dmodel + 8 - 72 + 127) / 128) * 128 + 72;
+  const size_t base = (size_t)THA_KB * a.kstr * 2 + (size_t)a.dmodel * THA_VSTR * 2 + (size_t)4 * d.heads * 16 * 2 * 4;
+  const size_t qbytes = (size_t)64 * a.kstr * 2;
+  a.q_in_lds = (base + qbytes <= 160 * 1024) ? 1 : 0;   // else Q fragments are re-read from L1/L2 per key tile
+  const size_t lds = base + (a.q_in_lds ? qbytes : 0);
+  if (lds > 160 * 1024) TFIMM_FAIL(TFIMM_EUNSUP, "talking_heads_attention: embed dim %d needs %zu bytes of LDS", a.dmodel, lds);
+  return d.hd == 32 ? launch_tha_heads<2>(a, lds, st) : launch_tha_heads<3>(a, lds, st);
+}
+
+extern "C" int tfimm_hip_class_attention(const void* q, const void* kv, void* out, int B, int n_tokens, int heads,
+                                         int hd, int ldq, int ldkv, int ldo, void* stream) {
+  if (!q || !kv || !out) TFIMM_FAIL(TFIMM_EINVAL, "class_attention: null pointer");
+  if (B <= 0 || n_tokens <= 0 || heads <= 0 || hd <= 0 || ldq < heads * hd || ldkv < 2 * heads * hd || ldo < heads * hd)
+    TFIMM_FAIL(TFIMM_EINVAL, "class_attention: bad shape");
+  if ((size_t)n_tokens * 4 > 64 * 1024) TFIMM_FAIL(TFIMM_EUNSUP, "class_attention: %d tokens", n_tokens);
+  const int64_t nblocks = (int64_t)B * heads;
+  if (nblocks > 0x7fffffffLL) TFIMM_FAIL(TFIMM_EINVAL, "class_attention: grid too large");
+  TFIMM_LAUNCH(class_attn_kernel, dim3((unsigned)nblocks), dim3(64), (size_t)n_tokens * 4, (hipStream_t)stream,
+               (const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)out, n_tokens, heads, hd, ldq, ldkv, ldo);
+  return 0;
+}
+
+extern "C" int tfimm_hip_copy_rows(const void* src, void* dst, int B, int src_rows, int dst_rows, int dst_row0, int d,
+                                   void* stream) {
+  if (!src || !dst) TFIMM_FAIL(TFIMM_EINVAL, "copy_rows: null pointer");
+  if (B <= 0 || src_rows <= 0 || d <= 0 || dst_row0 < 0 || dst_row0 + src_rows > dst_rows)
+    TFIMM_FAIL(TFIMM_EINVAL, "copy_rows: bad shape");
+  if ((d & 7) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) {   // element-wise catch-all
+    const int64_t total = (int64_t)B * src_rows * d;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    TFIMM_LAUNCH(copy_rows_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                 (bf16_t*)dst, total, src_rows, dst_rows, dst_row0, d);
+    return 0;
+  }
+  const int d8 = d / 8;
+  const int64_t total = (int64_t)B * src_rows * d8;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  TFIMM_LAUNCH(copy_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)src,
+               (uint4*)dst, total, src_rows, dst_rows, dst_row0, d8);
+  return 0;
+}

@@ -48,6 +48,15 @@ class AttnDesc(C.Structure):
     ]
 
 
+class ThaDesc(C.Structure):
+    _fields_ = [
+        ("qkv", C.c_void_p), ("out", C.c_void_p),
+        ("proj_l_w", C.c_void_p), ("proj_l_b", C.c_void_p), ("proj_w_w", C.c_void_p), ("proj_w_b", C.c_void_p),
+        ("batch", C.c_int32), ("n_tokens", C.c_int32), ("heads", C.c_int32), ("hd", C.c_int32),
+        ("scale", C.c_float),
+    ]
+
+
 # name -> (restype, argtypes); every symbol declared in include/tfimm_hip.h
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SYMBOLS = {
@@ -59,6 +68,9 @@ SYMBOLS = {
     "tfimm_hip_cast_input_pad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tfimm_hip_layernorm": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i64, _i64, _f, _vp]),
     "tfimm_hip_attention": (_i, [C.POINTER(AttnDesc), _vp]),
+    "tfimm_hip_talking_heads_attention": (_i, [C.POINTER(ThaDesc), _vp]),
+    "tfimm_hip_class_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "tfimm_hip_copy_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tfimm_hip_maxpool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tfimm_hip_mean_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "tfimm_hip_bcast_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

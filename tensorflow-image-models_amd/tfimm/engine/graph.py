@@ -103,7 +103,7 @@ class Program:
             a = op.attrs
             if op.kind == "gemm":
                 total += 2 * a["M"] * a["N"] * a["K_true"]
-            elif op.kind == "attention":
+            elif op.kind in ("attention", "talking_heads_attention"):
                 total += a["flops"]
             elif op.kind == "dwconv":
                 total += 2 * a["OH"] * a["OW"] * a["C"] * a["k"] * a["k"]
@@ -177,6 +177,7 @@ class Program:
 class Builder:
     def __init__(self, weights: Dict[str, np.ndarray]):
         self.w = weights
+        self._orig_w = weights
         self.p = Program()
 
     # -- weights ---------------------------------------------------------------------------
@@ -184,6 +185,14 @@ class Builder:
         if name not in self.w:
             raise KeyError(f"missing weight '{name}'")
         return np.asarray(self.w[name], dtype=np.float32)
+
+    def define(self, name: str, value: np.ndarray) -> str:
+        """Register a weight derived on the host (e.g. the k and v kernels of CaiT's ClassAttention
+        side by side, the q kernel with the attention scale folded in) under a new name."""
+        if self.w is self._orig_w:
+            self.w = dict(self._orig_w)
+        self.w[name] = np.asarray(value, dtype=np.float32)
+        return name
 
     def bn(self, prefix: str, eps: float):
         """Folded inference BatchNorm -> (scale, shift).  Keras BN: layers/factory.py:22-37."""
@@ -299,6 +308,7 @@ class Builder:
               residual: Optional[TRef] = None, out_f32=False, row_select: Optional[Tuple[int, int]] = None,
               in_cols: Optional[Tuple[int, int]] = None,
               out: Optional[TRef] = None, out_col: int = 0, out_scale: Optional[str] = None,
+              residual_row: Optional[int] = None, out_row: Optional[int] = None,
               cite="", name="") -> TRef:
         """tf.keras.layers.Dense (+ activation, + residual add).
 
@@ -306,6 +316,9 @@ class Builder:
         starting at ``first_row`` (e.g. the class token x[:, 0], vit.py:462) without a copy.
         ``out``/``out_col``: write into columns [out_col, out_col+N) of an existing tensor
         (tf.stack of the two DeiT heads, vit.py:474-476).
+        ``residual_row`` / ``out_row``: with one row per image, take the residual from / write the result
+        to that token row of a multi-row tensor (CaiT's class-token-only blocks update x[:, 0] of the
+        token tensor in place, cait.py:186-200).
         """
         p = self.p
         k = self.wget(kernel)
@@ -343,15 +356,25 @@ class Builder:
         else:
             attrs["out_col"] = out_col
         attrs["ldc"] = out.C
+        if out_row is not None:
+            assert rows == 1 and out.C == kout and out_row < out.rows
+            attrs["ldc"] = out.rows * out.C
+            attrs["out_byte_offset"] = out_row * out.C * out.itemsize
         consts = {"wt": p.new_const(wt, kernel)}
         if bvec is not None:
             consts["bias"] = p.new_const(bvec, kernel + ":bias")
         ins = [x]
         if residual is not None:
-            assert residual.C == kout and residual.rows == rows
+            assert residual.C == kout
             ins.append(residual)
             attrs["has_residual"] = True
             attrs["ldr"] = residual.C
+            if residual_row is not None:
+                assert rows == 1 and residual_row < residual.rows
+                attrs["ldr"] = residual.rows * residual.C
+                attrs["res_byte_offset"] = residual_row * residual.C * 2
+            else:
+                assert residual.rows == rows
         p.add("gemm", ins, out, consts, cite=cite, **attrs)
         return out
 
@@ -403,6 +426,35 @@ class Builder:
               window=window, shift=shift, res_h=res[0], res_w=res[1], n_tokens=qkv.rows,
               flops=4 * nseq * heads * n * n * hd)
         return out
+
+    def talking_heads_attention(self, qkv: TRef, heads: int, scale: float, prefix: str, cite="", name="") -> TRef:
+        """CaiT TalkingHeadAttention between its qkv and proj layers (cait.py:236-256); ``prefix`` holds
+        the proj_l / proj_w Dense(H -> H) layers."""
+        p = self.p
+        d = qkv.C // 3
+        hd = d // heads
+        out = p.new_tensor(qkv.rows, d, qkv.H, qkv.W, name=name or prefix)
+        consts = {}
+        for role, nm in (("wl", "proj_l/kernel"), ("bl", "proj_l/bias"), ("ww", "proj_w/kernel"), ("bw", "proj_w/bias")):
+            consts[role] = p.new_const(np.ascontiguousarray(self.wget(f"{prefix}/{nm}"), dtype=np.float32), f"{prefix}/{nm}")
+        n = qkv.rows
+        p.add("talking_heads_attention", [qkv], out, consts, cite=cite, heads=heads, hd=hd, scale=float(scale),
+              n_tokens=n, flops=4 * heads * n * n * hd + 4 * heads * heads * n * n)
+        return out
+
+    def class_attention(self, q: TRef, kv: TRef, heads: int, cite="", name="") -> TRef:
+        """CaiT ClassAttention core (cait.py:137-143): q one (pre-scaled) row per image, kv [tokens][2D]."""
+        d = q.C
+        assert q.rows == 1 and kv.C == 2 * d
+        out = self.p.new_tensor(1, d, name=name or "class_attn")
+        self.p.add("class_attention", [q, kv], out, cite=cite, heads=heads, hd=d // heads, n_tokens=kv.rows)
+        return out
+
+    def copy_rows(self, src: TRef, dst: TRef, dst_row0: int, cite="") -> None:
+        """dst[:, dst_row0 : dst_row0 + src.rows] = src (one operand of a tf.concat on the token axis)."""
+        assert src.C == dst.C and dst_row0 + src.rows <= dst.rows
+        self.p.add("copy_rows", [src, dst], dst, cite=cite, src_rows=src.rows, dst_rows=dst.rows, dst_row0=dst_row0,
+                   d=src.C)
 
     # -- pooling / misc ------------------------------------------------------------------------
     def maxpool(self, x: TRef, k: int, stride: int, pad: int, cite="") -> TRef:
@@ -582,7 +634,7 @@ class Plan:
                 d.wt = self.cptr(op.consts["wt"])
                 d.bias = self.cptr(op.consts.get("bias"))
                 out_t = prog.tensors[op.output]
-                out_ptr = self.tptr(out_t.id) + a.get("out_col", 0) * out_t.itemsize
+                out_ptr = self.tptr(out_t.id) + a.get("out_col", 0) * out_t.itemsize + a.get("out_byte_offset", 0)
                 d.out = out_ptr
                 d.ldc = a.get("ldc", out_t.C)
                 d.out_f32 = a["out_f32"]
@@ -590,7 +642,7 @@ class Plan:
                 d.act_after_res = 1 if a["act_after_res"] else 0
                 idx = 1
                 if a.get("has_residual"):
-                    d.residual = self.tptr(op.inputs[idx])
+                    d.residual = self.tptr(op.inputs[idx]) + a.get("res_byte_offset", 0)
                     idx += 1
                     d.ldr = a["ldr"]
                 elif "residual" in op.consts:
@@ -623,6 +675,24 @@ class Plan:
                 d.window, d.shift, d.res_h, d.res_w = a["window"], a["shift"], a["res_h"], a["res_w"]
                 self._keepalive.append(d)
                 self.calls.append((lib.tfimm_hip_attention, (C.byref(d),)))
+            elif k == "talking_heads_attention":
+                d = ffi.ThaDesc()
+                d.qkv = self.tptr(op.inputs[0])
+                d.out = self.tptr(op.output)
+                d.proj_l_w, d.proj_l_b = self.cptr(op.consts["wl"]), self.cptr(op.consts["bl"])
+                d.proj_w_w, d.proj_w_b = self.cptr(op.consts["ww"]), self.cptr(op.consts["bw"])
+                d.batch, d.n_tokens, d.heads, d.hd, d.scale = B, a["n_tokens"], a["heads"], a["hd"], a["scale"]
+                self._keepalive.append(d)
+                self.calls.append((lib.tfimm_hip_talking_heads_attention, (C.byref(d),)))
+            elif k == "class_attention":
+                dm = a["heads"] * a["hd"]
+                self.calls.append((lib.tfimm_hip_class_attention,
+                                   (self.tptr(op.inputs[0]), self.tptr(op.inputs[1]), self.tptr(op.output), B,
+                                    a["n_tokens"], a["heads"], a["hd"], dm, 2 * dm, dm)))
+            elif k == "copy_rows":
+                self.calls.append((lib.tfimm_hip_copy_rows,
+                                   (self.tptr(op.inputs[0]), self.tptr(op.output), B, a["src_rows"], a["dst_rows"],
+                                    a["dst_row0"], a["d"])))
             elif k == "maxpool":
                 self.calls.append((lib.tfimm_hip_maxpool,
                                    (self.tptr(op.inputs[0]), self.tptr(op.output), B, a["H"], a["W"], a["C"],

@@ -20,6 +20,7 @@ MODELS = [("vit_test_model", 2), ("deit_test_model", 2), ("vit_hd64_test_model",
           ("resnet_test_model_2", 2), ("resnet50_mini_test_model", 2), ("seresnet_test_model", 2),
           ("swin_test_model", 2), ("swin_shift_test_model", 2), ("efficientnet_test_model", 2),
           ("efficientnet_same_test_model", 2), ("convnext_odd_test_model", 2), ("convnext_wide_test_model", 2),
+          ("cait_test_model", 2), ("cait_hd48_test_model", 2), ("cait_hd32_test_model", 2),
           ("vit_tiny_patch16_224", 1)]
 
 

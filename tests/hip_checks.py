@@ -320,6 +320,89 @@ CASES["attn_50_hd32"] = lambda: _attn_case(2, 50, 4, 32, 66)
 CASES["attn_hd48"] = lambda: _attn_case(2, 33, 2, 48, 67)
 
 
+def _tha_ref(qkv, B, N, heads, hd, scale, wl, bl, ww, bw):
+    """TalkingHeadAttention.call between qkv and proj (reference cait.py:236-256), float64."""
+    q = qkv.reshape(B, N, 3, heads, hd).transpose(2, 0, 3, 1, 4).astype(np.float64)
+    s = (scale * q[0]) @ q[1].transpose(0, 1, 3, 2)                  # (B, H, N, N)
+    s = s.transpose(0, 2, 3, 1) @ wl.astype(np.float64) + bl         # proj_l over the head axis
+    s = s.transpose(0, 3, 1, 2)
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(-1, keepdims=True)
+    p = p.transpose(0, 2, 3, 1) @ ww.astype(np.float64) + bw         # proj_w
+    p = p.transpose(0, 3, 1, 2)
+    o = p @ q[2]
+    return o.transpose(0, 2, 1, 3).reshape(B * N, heads * hd)
+
+
+def _tha_case(B, N, heads, hd, seed):
+    import hip_ops as H
+    r = _rng(seed)
+    qkv = _bf(r.standard_normal((B * N, 3 * heads * hd)))
+    wl = (r.standard_normal((heads, heads)) / heads ** 0.5 + np.eye(heads)).astype(np.float32)
+    ww = (r.standard_normal((heads, heads)) / heads ** 0.5 + np.eye(heads)).astype(np.float32)
+    bl = (0.3 * r.standard_normal(heads)).astype(np.float32)
+    bw = (0.02 * r.standard_normal(heads)).astype(np.float32)
+    scale = hd ** -0.5
+    ref = _tha_ref(qkv, B, N, heads, hd, scale, wl, bl, ww, bw)
+    got = H.talking_heads_attention(H.dev_bf16(qkv), B, N, heads, hd, scale, H.dev_f32(wl), H.dev_f32(bl),
+                                    H.dev_f32(ww), H.dev_f32(bw))
+    H.sync()
+    return _err(_cpu(got), ref), 1.5e-2   # mixed probabilities are rounded to bf16 before P.V
+
+
+CASES["tha_196_h4_hd48"] = lambda: _tha_case(2, 196, 4, 48, 160)
+CASES["tha_50_h6_hd48_tail"] = lambda: _tha_case(3, 50, 6, 48, 161)
+CASES["tha_64_h8_hd48_exact"] = lambda: _tha_case(1, 64, 8, 48, 162)
+CASES["tha_100_h16_hd48_two_groups"] = lambda: _tha_case(1, 100, 16, 48, 163)
+CASES["tha_33_h2_hd32"] = lambda: _tha_case(2, 33, 2, 32, 164)
+CASES["tha_17_h3_hd32"] = lambda: _tha_case(2, 17, 3, 32, 165)
+CASES["tha_577_h4_hd48_long"] = lambda: _tha_case(1, 577, 4, 48, 166)
+CASES["tha_9_h1_hd32"] = lambda: _tha_case(2, 9, 1, 32, 167)
+CASES["tha_generic_16_h2_hd2"] = lambda: _tha_case(3, 16, 2, 2, 168)       # the reference's mini: catch-all kernel
+CASES["tha_generic_40_h5_hd24"] = lambda: _tha_case(2, 40, 5, 24, 169)
+
+
+def _class_attn_case(B, N, heads, hd, seed):
+    import hip_ops as H
+    r = _rng(seed)
+    D = heads * hd
+    q = _bf(r.standard_normal((B, D)) * hd ** -0.5)                   # already scaled, as the lowering hands it over
+    kv = _bf(r.standard_normal((B * N, 2 * D)))
+    qh = q.reshape(B, heads, 1, hd).astype(np.float64)
+    k = kv[:, :D].reshape(B, N, heads, hd).transpose(0, 2, 1, 3).astype(np.float64)
+    v = kv[:, D:].reshape(B, N, heads, hd).transpose(0, 2, 1, 3).astype(np.float64)
+    s = qh @ k.transpose(0, 1, 3, 2)                                  # (B, H, 1, N)   cait.py:137
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(-1, keepdims=True)
+    ref = (p @ v).transpose(0, 2, 1, 3).reshape(B, D)                 # cait.py:141-143
+    got = H.class_attention(H.dev_bf16(q), H.dev_bf16(kv), B, N, heads, hd)
+    H.sync()
+    return _err(_cpu(got), ref), TOL_BF16
+
+
+CASES["class_attn_197_h4_hd48"] = lambda: _class_attn_case(3, 197, 4, 48, 170)
+CASES["class_attn_785_h16_hd48"] = lambda: _class_attn_case(2, 785, 16, 48, 171)
+CASES["class_attn_10_h2_hd32"] = lambda: _class_attn_case(2, 10, 2, 32, 172)
+
+
+def _copy_rows_case():
+    import hip_ops as H
+    r = _rng(173)
+    src = _bf(r.standard_normal((3, 20, 48)))
+    dst0 = _bf(r.standard_normal((3, 22, 48)))
+    dst = H.dev_bf16(dst0.copy())
+    H.copy_rows(H.dev_bf16(src), dst, 1)
+    H.sync()
+    want = dst0.copy()
+    want[:, 1:21] = src
+    return float(np.abs(_cpu(dst) - want).max()), 0.0
+
+
+CASES["copy_rows_concat"] = _copy_rows_case
+
+
 def _swin_ref(x_qkv, B, Hr, Wr, heads, hd, ws, shift, table):
     """Literal restatement of swin.py:287-318 + WindowAttention.call on a packed qkv tensor."""
     C = heads * hd

@@ -104,6 +104,29 @@ def attention(qkv, batch, n_tokens, heads, hd, scale, window=0, shift=0, res=(0,
     return out
 
 
+def talking_heads_attention(qkv, batch, n_tokens, heads, hd, scale, wl, bl, ww, bw):
+    out = torch.empty(batch * n_tokens, heads * hd, dtype=torch.bfloat16, device=DEV)
+    d = ffi.ThaDesc()
+    d.qkv, d.out = ptr(qkv), ptr(out)
+    d.proj_l_w, d.proj_l_b, d.proj_w_w, d.proj_w_b = ptr(wl), ptr(bl), ptr(ww), ptr(bw)
+    d.batch, d.n_tokens, d.heads, d.hd, d.scale = batch, n_tokens, heads, hd, float(scale)
+    ffi.check(lib.tfimm_hip_talking_heads_attention(C.byref(d), stream()), "talking_heads_attention")
+    return out
+
+
+def class_attention(q, kv, batch, n_tokens, heads, hd):
+    out = torch.empty(batch, heads * hd, dtype=torch.bfloat16, device=DEV)
+    ffi.check(lib.tfimm_hip_class_attention(ptr(q), ptr(kv), ptr(out), batch, n_tokens, heads, hd, q.shape[-1],
+                                            kv.shape[-1], heads * hd, stream()), "class_attention")
+    return out
+
+
+def copy_rows(src, dst, dst_row0):
+    B, R, D = src.shape
+    ffi.check(lib.tfimm_hip_copy_rows(ptr(src), ptr(dst), B, R, dst.shape[1], dst_row0, D, stream()), "copy_rows")
+    return dst
+
+
 def cast_input(x, c_out):
     B, H, W, Cin = x.shape
     out = torch.empty(B, H, W, c_out, dtype=torch.bfloat16, device=DEV)

@@ -6,6 +6,7 @@ tests/models/architectures.py:33-361: tiny configs registered through the real
 assumptions.  The second block closes coverage holes the survey found in the reference's
 minis: head dim 64, default 7x7 stem + Bottleneck + downsample_conv, SE.
 """
+from tfimm.architectures.cait import CaiT, CaiTConfig
 from tfimm.architectures.convnext import ConvNeXt, ConvNeXtConfig
 from tfimm.architectures.efficientnet import EfficientNet, EfficientNetConfig
 from tfimm.architectures.resnet import ResNet, ResNetConfig
@@ -98,6 +99,24 @@ if not is_model("vit_test_model"):
         """16-byte-aligned channel counts (vector kernels), ConvMLP blocks, odd input size, 3 stages."""
         return ConvNeXt, ConvNeXtConfig(name="convnext_wide_test_model", nb_classes=10, input_size=(72, 56),
                                         embed_dim=(16, 32, 64), nb_blocks=(2, 1, 2), conv_mlp_block=True)
+
+    @register_model
+    def cait_test_model():
+        """Same hyper-parameters as the reference's mini (tests/models/architectures.py:59-69): head dim 2."""
+        return CaiT, CaiTConfig(name="cait_test_model", nb_classes=12, input_size=(32, 32), patch_size=8, embed_dim=4,
+                                nb_blocks=2, nb_heads=2)
+
+    @register_model
+    def cait_hd48_test_model():
+        """Head dim 48 like every published CaiT (MFMA talking-heads kernel), 3 heads, 5 x 3 patch grid."""
+        return CaiT, CaiTConfig(name="cait_hd48_test_model", nb_classes=10, input_size=(80, 48), patch_size=16,
+                                embed_dim=144, nb_blocks=3, nb_heads=3)
+
+    @register_model
+    def cait_hd32_test_model():
+        """Head dim 32, 8 heads, no qkv bias, 81 patch tokens (key tail of 17 in the last 32-key block)."""
+        return CaiT, CaiTConfig(name="cait_hd32_test_model", nb_classes=10, input_size=(72, 72), patch_size=8,
+                                embed_dim=256, nb_blocks=2, nb_heads=8, qkv_bias=False)
 
     @register_model
     def seresnet_test_model():

@@ -48,7 +48,7 @@ def test_engine_matches_golden(name):
     got = model(x).numpy().reshape(ref.shape)
     # embed_dim = 4 minis: every LayerNorm runs over 4 bf16-rounded values, one ulp of the residual
     # stream moves a normalised value by percent -- they get twice the bar (see test_gpu_models.py)
-    tol = 2 * mc.TOL_LOGITS if model.cfg.name in ("vit_test_model", "deit_test_model") else mc.TOL_LOGITS
+    tol = 2 * mc.TOL_LOGITS if model.cfg.name in ("vit_test_model", "deit_test_model", "cait_test_model") else mc.TOL_LOGITS
     assert mc.rel_err(got, ref) <= tol
     if tol == mc.TOL_LOGITS:
         assert (got.argmax(-1) == ref.argmax(-1)).all()

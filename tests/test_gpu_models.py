@@ -9,11 +9,12 @@ pytestmark = pytest.mark.gpu
 
 MINIS = ["vit_test_model", "deit_test_model", "vit_hd64_test_model", "resnet_test_model_1", "resnet_test_model_2",
          "resnet50_mini_test_model", "seresnet_test_model", "swin_test_model", "swin_shift_test_model",
-         "efficientnet_test_model", "efficientnet_same_test_model", "convnext_odd_test_model", "convnext_wide_test_model"]
+         "efficientnet_test_model", "efficientnet_same_test_model", "convnext_odd_test_model", "convnext_wide_test_model",
+         "cait_hd48_test_model", "cait_hd32_test_model"]
 FULL = [("vit_tiny_patch16_224", 2), ("deit_tiny_distilled_patch16_224", 2), ("resnet18", 2), ("resnet50", 2),
         ("vit_base_patch16_224", 1), ("swin_tiny_patch4_window7_224", 2), ("efficientnet_b0", 2),
         ("swin_base_patch4_window7_224", 1), ("efficientnet_b4", 1), ("efficientnet_v2_b0", 2), ("mobilenet_v2_100", 2), ("convnext_tiny", 2),
-        ("convnext_base_384_in22ft1k", 1)]
+        ("convnext_base_384_in22ft1k", 1), ("cait_xxs24_224", 2), ("cait_s24_224", 1), ("cait_m36_384", 1)]
 
 
 @pytest.mark.parametrize("name", MINIS)
@@ -45,6 +46,17 @@ def test_convnext_other_input_size_and_features():
     r = mc.compare_model("convnext_wide_test_model", batch=2, size=(40, 64), features=True)
     bad = {k: v for k, v in r.items() if (k.startswith("feat:") or k == "logits") and v > mc.TOL_LOGITS}
     assert not bad, bad
+
+
+def test_cait_features_and_reference_mini():
+    """every returned feature of the hd-48 mini (incl. the in-place class-token blocks' snapshots); the
+    reference's own 4-channel mini runs through the catch-all kernels and gets the looser bar (see
+    test_features_vit_mini)."""
+    r = mc.compare_model("cait_hd48_test_model", batch=2, features=True)
+    bad = {k: v for k, v in r.items() if (k.startswith("feat:") or k == "logits") and v > mc.TOL_LOGITS}
+    assert not bad, bad
+    r = mc.compare_model("cait_test_model", batch=3)
+    assert r["logits"] <= 2 * mc.TOL_LOGITS, r
 
 
 def test_micro_batch_equals_full_batch():
