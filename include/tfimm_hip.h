@@ -184,15 +184,17 @@ TFIMM_API int tfimm_hip_attention(const tfimm_attn_desc* d, void* stream);
  *     w[b,g,i,j]  = sum_h' a[b,h',i,j] * proj_w_w[h'][g] + proj_w_b[g]
  *     out[b,i,g,:] = sum_j w[b,g,i,j] * v[b,j,g,:]
  * qkv packed as for tfimm_hip_attention (bf16 [rows][3*heads*hd], rows = batch * n_tokens);
- * proj_*_w are the Keras kernels [heads_in][heads_out] in fp32.  MFMA kernel for hd in {32, 48} (every
+ * proj_*_w / proj_*_b are the Keras kernels [heads_in][heads_out] and biases in fp32 and are HOST
+ * pointers (heads <= 16): the library copies them into the kernel's argument segment at launch, so
+ * they are read with scalar loads -- they are layer weights, known on the host when the plan is built.  MFMA kernel for hd in {32, 48} (every
  * CaiT configuration has hd = 48) and heads in {1, 2, 3, 4, 6, 8, 16}; any other shape takes a plain
  * fp32 kernel (one workgroup per query row) as long as 2 * heads * n_tokens floats fit in LDS.
  * ------------------------------------------------------------------------------------- */
 typedef struct tfimm_tha_desc {
   const void* qkv;
   void* out;                /* bf16 [rows][heads*hd] */
-  const float* proj_l_w;    /* fp32 [heads][heads] */
-  const float* proj_l_b;    /* fp32 [heads] */
+  const float* proj_l_w;    /* HOST fp32 [heads][heads] */
+  const float* proj_l_b;    /* HOST fp32 [heads] */
   const float* proj_w_w;
   const float* proj_w_b;
   int32_t batch, n_tokens, heads, hd;

@@ -18,11 +18,17 @@
 //     the logits, normalises, applies the second mixing and multiplies with V.  QK^T is cheap next
 //     to the mixing (H^2 VALU FMAs per position against 2 * hd MFMA MACs).
 //   * P (accumulator layout: query = lane & 15, keys 4g .. 4g+3) is exactly the "b" operand of
-//     v_mfma_f32_16x16x16_bf16, with V^T (staged transposed in LDS) as "a": O^T = V^T . P^T needs
-//     no shuffle.  Output accumulators are 4 * hd/16 registers per value head, so value heads are
+//     v_mfma_f32_16x16x16_bf16; the matching V^T "a" operand comes out of the row-major V block
+//     with one transposing LDS read (ds_read_b64_tr_b16): O^T = V^T . P^T needs no shuffle and the
+//     staging no transposition.  Output accumulators are 4 * hd/16 registers per value head, so value heads are
 //     processed in groups of <= 8 (H = 16: pass 2 runs twice).
-//   * K block [32 keys][D] and V^T block [D][32 keys] of the image are staged per workgroup; the
-//     workgroup's Q rows live in LDS when they fit, else Q fragments come from L1/L2.
+//   * K block and V block [32 keys][D] of the image are staged per workgroup with plain 16-byte
+//     copies (8 threads per row: no index divisions); heads sit at a stride padded to whole 32-wide
+//     k-steps with zeroed pads, so fragment reads need no masking.  The workgroup's Q rows live in
+//     LDS when they fit, else Q fragments come from L1/L2.
+//   Measured on the first version (B=256, N=196, H=4): VALU 88 % busy, 68 % of the LDS cycles bank
+//   conflicts -- index divisions and 2-byte transposing stores in the staging, masks on every
+//   fragment; all three are gone in this layout.
 #include "common.h"
 
 #include <cstdlib>
@@ -31,33 +37,46 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
 
+// The two H x H head-mixing layers travel BY VALUE in the kernel argument segment and are copied
+// to LDS once per workgroup; the mixing loops read them from there (broadcast ds_read, re-read for
+// every key tile).  Both alternatives cost the second wave per SIMD: through global pointers hipcc
+// hoists all 2 H^2 weights into VGPRs for the whole key loop, as SGPRs (kernarg scalar loads) they
+// overflow the scalar file and every use becomes a v_readlane from a spill register.
+struct ThaWeights {
+  float wl[256], bl[16];   // proj_l kernel [H_in][H_out] (row stride H), bias
+  float ww[256], bw[16];   // proj_w
+};
+
 struct ThaArgs {
   const bf16_t* qkv;
   bf16_t* out;
-  const float* wl; const float* bl;   // proj_l kernel [H_in][H_out], bias [H]
-  const float* ww; const float* bw;   // proj_w
   int batch, n, heads;
   float scale;
   int ld, dmodel;
   int qchunks;
-  int kstr;       // LDS row stride (elements) of the K / Q blocks
+  int kstr;       // LDS row stride (elements) of the K / Q blocks (heads padded to whole 32-wide k-steps)
+  int vstr;       // LDS row stride of the V block
   int q_in_lds;
 };
 
 constexpr int THA_KB = 32;        // keys staged per step
-constexpr int THA_VSTR = THA_KB + 8;
 
-template <int H, int HG, int DT>
-__global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p) {
+template <int H, int HG, int DT, bool QLDS>
+__global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p, const ThaWeights w) {
   constexpr int HD = DT * 16;
   constexpr int KS = (HD + 31) / 32;
+  constexpr int HP = KS * 32;       // head stride of the K / Q blocks in LDS: head dim padded to whole k-steps
+  constexpr int CPH = HD / 8;       // 16-byte chunks per head row
   constexpr float LOG2E = 1.4426950408889634f;
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
   extern __shared__ __attribute__((aligned(16))) char smem_tha[];
   const int D = p.dmodel;
-  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_tha);                     // [THA_KB][kstr]
-  bf16_t* Vt = Ks + THA_KB * p.kstr;                                     // [D][THA_VSTR]
-  float* St = reinterpret_cast<float*>(Vt + (size_t)D * THA_VSTR);       // [4 waves][H][16][2]
-  bf16_t* Qs = reinterpret_cast<bf16_t*>(St + 4 * H * 16 * 2);           // [64][kstr] (q_in_lds)
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_tha);                     // [THA_KB][kstr], heads at stride HP
+  bf16_t* Vs = Ks + THA_KB * p.kstr;                                     // [THA_KB][vstr], row-major V
+  float* St = reinterpret_cast<float*>(Vs + THA_KB * p.vstr);            // [4 waves][H][16][2]
+  float* Wm = St + 4 * H * 16 * 2;                                       // wl [H][H], bl [H], ww [H][H], bw [H]
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(Wm + (2 * (H * H + H) + 3) / 4 * 4);   // [64][kstr] (q_in_lds)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -68,44 +87,72 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p) {
   const bool q_ok = q < p.n;
   const int CH = D / 8;             // 16-byte chunks per token row of one of q / k / v
 
-  if (p.q_in_lds) {
-    for (int id = tid; id < 64 * CH; id += 256) {
-      const int r = id / CH, c = id - r * CH;
-      const int t = qc * 64 + r;
-      uint4 u = make_uint4(0u, 0u, 0u, 0u);
-      if (t < p.n) u = *reinterpret_cast<const uint4*>(p.qkv + (row0 + t) * p.ld + c * 8);
-      *reinterpret_cast<uint4*>(&Qs[r * p.kstr + c * 8]) = u;
+  for (int id = tid; id < H * H; id += 256) {
+    Wm[id] = w.wl[id];
+    Wm[H * H + H + id] = w.ww[id];
+  }
+  if (tid < H) {
+    Wm[H * H + tid] = w.bl[tid] * LOG2E;
+    Wm[2 * H * H + H + tid] = w.bw[tid];
+  }
+  // staging map (no divisions): 8 threads per row, thread (row = tid >> 3) walks chunks (tid & 7) + 8 j;
+  // chunk c of a token row belongs to head c / CPH and lands at column head * HP + (c % CPH) * 8
+  const int srow = tid >> 3, sc0 = tid & 7;
+  if (HP != HD) {   // the pad columns of every head stay zero for the whole kernel
+    for (int id = tid; id < THA_KB * H; id += 256) {
+      const int r = id / H, h = id - r * H;
+#pragma unroll
+      for (int e = HD; e < HP; e += 8) *reinterpret_cast<uint4*>(&Ks[r * p.kstr + h * HP + e]) = make_uint4(0u, 0u, 0u, 0u);
     }
   }
+  if (QLDS) {
+    for (int rr = srow; rr < 64; rr += 32) {
+      const int t = qc * 64 + rr;
+      for (int c = sc0; c < CH; c += 8) {
+        uint4 u = make_uint4(0u, 0u, 0u, 0u);
+        if (t < p.n) u = *reinterpret_cast<const uint4*>(p.qkv + (row0 + t) * p.ld + c * 8);
+        const int h = c / CPH;
+        *reinterpret_cast<uint4*>(&Qs[rr * p.kstr + h * HP + (c - h * CPH) * 8]) = u;
+      }
+      if (HP != HD) {
+        for (int h = sc0; h < H; h += 8)
+#pragma unroll
+          for (int e = HD; e < HP; e += 8) *reinterpret_cast<uint4*>(&Qs[rr * p.kstr + h * HP + e]) = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  }
+  // (these LDS offsets are made opaque once per key tile: fragments, softmax statistics and mixing
+  // weights are then re-read from LDS for every tile instead of being hoisted and kept live across the
+  // key loop.  Offsets, not pointers: an opaque POINTER loses its address space and turns every read
+  // into a flat load)
+  int qs_off = (wave * 16 + l15) * p.kstr;
+  int st_off = (wave * H * 16 + l15) * 2;
+  int wm_off = 0;
   // Q fragment of head h, k-step ks for this lane's query: d = ks*32 + g*8 .. +8 (zero beyond HD)
   auto q_frag = [&](int h, int ks) -> bf16x8 {
     const int d0 = ks * 32 + g * 8;
-    uint4 u = make_uint4(0u, 0u, 0u, 0u);
-    if (d0 < HD) {
-      if (p.q_in_lds) u = *reinterpret_cast<const uint4*>(&Qs[(wave * 16 + l15) * p.kstr + h * HD + d0]);
-      else if (q_ok) u = *reinterpret_cast<const uint4*>(p.qkv + (row0 + q) * p.ld + h * HD + d0);
-    }
+    if (QLDS) return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Qs[qs_off + h * HP + d0]));
+    // from L1/L2: lanes whose k-group lies beyond the head read a valid address and are masked to zero
+    const int dc = d0 < HD ? d0 : 0;
+    const unsigned keep = (d0 < HD && q_ok) ? 0xffffffffu : 0u;
+    uint4 u = *reinterpret_cast<const uint4*>(p.qkv + (row0 + (q_ok ? q : 0)) * p.ld + h * HD + dc);
+    u.x &= keep; u.y &= keep; u.z &= keep; u.w &= keep;
     return __builtin_bit_cast(bf16x8, u);
   };
 
   auto stage = [&](int kb, bool with_v) {
-    __syncthreads();   // previous block fully consumed (and Qs written, first time)
-    for (int id = tid; id < THA_KB * CH; id += 256) {
-      const int key = id / CH, c = id - key * CH;
-      const int t = kb + key;
+    __syncthreads();   // previous block fully consumed (and Qs / Wm written, first time)
+    const int t = kb + srow;
+    const bf16_t* kp = p.qkv + (row0 + (t < p.n ? t : 0)) * p.ld + D;
+    for (int c = sc0; c < CH; c += 8) {
       uint4 ku = make_uint4(0u, 0u, 0u, 0u), vu = make_uint4(0u, 0u, 0u, 0u);
       if (t < p.n) {
-        const bf16_t* kp = p.qkv + (row0 + t) * p.ld + D + c * 8;
-        ku = *reinterpret_cast<const uint4*>(kp);
-        if (with_v) vu = *reinterpret_cast<const uint4*>(kp + D);
+        ku = *reinterpret_cast<const uint4*>(kp + c * 8);
+        if (with_v) vu = *reinterpret_cast<const uint4*>(kp + D + c * 8);
       }
-      *reinterpret_cast<uint4*>(&Ks[key * p.kstr + c * 8]) = ku;
-      if (with_v) {
-        const uint32_t vw[4] = {vu.x, vu.y, vu.z, vu.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          Vt[(c * 8 + e) * THA_VSTR + key] = (bf16_t)((vw[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-      }
+      const int h = c / CPH;
+      *reinterpret_cast<uint4*>(&Ks[srow * p.kstr + h * HP + (c - h * CPH) * 8]) = ku;
+      if (with_v) *reinterpret_cast<uint4*>(&Vs[srow * p.vstr + c * 8]) = vu;
     }
     __syncthreads();
   };
@@ -113,24 +160,36 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p) {
   // mixed logits (log2 units) of key tile t of the staged block, all H mixed heads
   const float cs = p.scale * LOG2E;
   auto logits = [&](int kb, int t, f32x4* mixed) __attribute__((always_inline)) {
+    asm volatile("" : "+v"(qs_off), "+v"(st_off), "+v"(wm_off));
+    const float* wm = Wm + wm_off;
 #pragma unroll
     for (int hp = 0; hp < H; ++hp) {
-      const float b = p.bl[hp] * LOG2E;
+      const float b = wm[H * H + hp];
       mixed[hp] = (f32x4){b, b, b, b};
     }
-#pragma unroll
-    for (int h = 0; h < H; ++h) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // fragments of head h + 1 are requested before head h is multiplied (one head of lookahead hides
+    // the LDS latency); the scheduling barrier keeps hipcc from hoisting ALL heads' fragments to the
+    // top, which costs 16 H registers and with them the second wave per SIMD
+    bf16x8 kf[2][KS], qf[2][KS];
+    auto frags = [&](int h, int buf) __attribute__((always_inline)) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const int d0 = ks * 32 + g * 8;
-        uint4 ku = make_uint4(0u, 0u, 0u, 0u);
-        if (d0 < HD) ku = *reinterpret_cast<const uint4*>(&Ks[(t * 16 + l15) * p.kstr + h * HD + d0]);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ku), q_frag(h, ks), acc, 0, 0, 0);
+        kf[buf][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(&Ks[(t * 16 + l15) * p.kstr + h * HP + ks * 32 + g * 8]));
+        qf[buf][ks] = q_frag(h, ks);
       }
+    };
+    frags(0, 0);
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      if (h + 1 < H) frags(h + 1, (h + 1) & 1);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[h & 1][ks], qf[h & 1][ks], acc, 0, 0, 0);
       acc *= cs;
 #pragma unroll
-      for (int hp = 0; hp < H; ++hp) mixed[hp] += p.wl[h * H + hp] * acc;
+      for (int hp = 0; hp < H; ++hp) mixed[hp] += wm[h * H + hp] * acc;
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (kb + THA_KB > p.n) {   // last block: keys beyond the sequence take no part in the softmax
 #pragma unroll
@@ -149,7 +208,7 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p) {
     for (int hp = 0; hp < H; ++hp) { m_run[hp] = -1e30f; l_run[hp] = 0.f; }
     for (int kb = 0; kb < p.n; kb += THA_KB) {
       stage(kb, false);
-#pragma unroll
+#pragma unroll 1
       for (int t = 0; t < THA_KB / 16; ++t) {
         f32x4 mixed[H];
         logits(kb, t, mixed);
@@ -157,8 +216,9 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p) {
         for (int hp = 0; hp < H; ++hp) {
           const f32x4 v = mixed[hp];
           const float m_new = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), m_run[hp]);
-          l_run[hp] = l_run[hp] * __builtin_amdgcn_exp2f(m_run[hp] - m_new) + __builtin_amdgcn_exp2f(v[0] - m_new) + __builtin_amdgcn_exp2f(v[1] - m_new) +
-                      __builtin_amdgcn_exp2f(v[2] - m_new) + __builtin_amdgcn_exp2f(v[3] - m_new);
+          l_run[hp] = l_run[hp] * __builtin_amdgcn_exp2f(m_run[hp] - m_new) + __builtin_amdgcn_exp2f(v[0] - m_new) +
+                      __builtin_amdgcn_exp2f(v[1] - m_new) + __builtin_amdgcn_exp2f(v[2] - m_new) +
+                      __builtin_amdgcn_exp2f(v[3] - m_new);
           m_run[hp] = m_new;
         }
       }
@@ -187,31 +247,34 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p) {
       for (int dt = 0; dt < DT; ++dt) o[i][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int kb = 0; kb < p.n; kb += THA_KB) {
       stage(kb, true);
-#pragma unroll
+#pragma unroll 1
       for (int t = 0; t < THA_KB / 16; ++t) {
         f32x4 pr[H];
         logits(kb, t, pr);
 #pragma unroll
         for (int hp = 0; hp < H; ++hp) {
-          const float m = St[((wave * H + hp) * 16 + l15) * 2 + 0];
-          const float il = St[((wave * H + hp) * 16 + l15) * 2 + 1];
+          const float m = St[st_off + hp * 32 + 0];
+          const float il = St[st_off + hp * 32 + 1];
 #pragma unroll
           for (int r = 0; r < 4; ++r) pr[hp][r] = __builtin_amdgcn_exp2f(pr[hp][r] - m) * il;
         }
+        // V^T fragments by transposing LDS reads: lane (l15, g) supplies the address of the 8-byte piece
+        // (key 4g + l15/4, d 4*(l15%4)..+3) and receives keys 4g..4g+3 at d = l15 -- the MFMA "a" operand
+        const char* vbase = reinterpret_cast<const char*>(Vs) + ((t * 16 + g * 4 + (l15 >> 2)) * p.vstr + (l15 & 3) * 4) * 2;
 #pragma unroll
         for (int i = 0; i < HG; ++i) {
           const int hq = hq0 + i;
-          const float b = p.bw[hq];
+          const float b = Wm[wm_off + 2 * H * H + H + hq];
           f32x4 a = {b, b, b, b};
 #pragma unroll
-          for (int hp = 0; hp < H; ++hp) a += p.ww[hp * H + hq] * pr[hp];
+          for (int hp = 0; hp < H; ++hp) a += Wm[wm_off + H * H + H + hp * H + hq] * pr[hp];
           // keys beyond the sequence carry the bias b, but their V rows are staged as zeros
           const uint2 pu = make_uint2(pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]));
           const bf16x4_t pf = __builtin_bit_cast(bf16x4_t, pu);
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
-            const uint2 vu = *reinterpret_cast<const uint2*>(&Vt[(hq * HD + dt * 16 + l15) * THA_VSTR + t * 16 + g * 4]);
-            o[i][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16x4_t, vu), pf, o[i][dt], 0, 0, 0);
+            const s16x4 vf = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vbase + (hq * HD + dt * 16) * 2));
+            o[i][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(bf16x4_t, vf), pf, o[i][dt], 0, 0, 0);
           }
         }
       }
@@ -231,29 +294,34 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p) {
   }
 }
 
-template <int H, int HG, int DT>
-int launch_tha(const ThaArgs& a, size_t lds, hipStream_t st) {
+template <int H, int HG, int DT, bool QLDS>
+int launch_tha_q(const ThaArgs& a, const ThaWeights& w, size_t lds, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)tha_kernel<H, HG, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)tha_kernel<H, HG, DT, QLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
   const int64_t nblocks = (int64_t)a.batch * a.qchunks;
   if (nblocks > 0x7fffffffLL) TFIMM_FAIL(TFIMM_EINVAL, "talking_heads_attention: grid too large");
-  TFIMM_LAUNCH((tha_kernel<H, HG, DT>), dim3((unsigned)nblocks), dim3(256), lds, st, a);
+  TFIMM_LAUNCH((tha_kernel<H, HG, DT, QLDS>), dim3((unsigned)nblocks), dim3(256), lds, st, a, w);
   return 0;
 }
 
+template <int H, int HG, int DT>
+int launch_tha(const ThaArgs& a, const ThaWeights& w, size_t lds, hipStream_t st) {
+  return a.q_in_lds ? launch_tha_q<H, HG, DT, true>(a, w, lds, st) : launch_tha_q<H, HG, DT, false>(a, w, lds, st);
+}
+
 template <int DT>
-int launch_tha_heads(const ThaArgs& a, size_t lds, hipStream_t st) {
+int launch_tha_heads(const ThaArgs& a, const ThaWeights& w, size_t lds, hipStream_t st) {
   switch (a.heads) {
-    case 1: return launch_tha<1, 1, DT>(a, lds, st);
-    case 2: return launch_tha<2, 2, DT>(a, lds, st);
-    case 3: return launch_tha<3, 3, DT>(a, lds, st);
-    case 4: return launch_tha<4, 4, DT>(a, lds, st);
-    case 6: return launch_tha<6, 6, DT>(a, lds, st);
-    case 8: return launch_tha<8, 8, DT>(a, lds, st);
-    case 16: return launch_tha<16, 8, DT>(a, lds, st);
+    case 1: return launch_tha<1, 1, DT>(a, w, lds, st);
+    case 2: return launch_tha<2, 2, DT>(a, w, lds, st);
+    case 3: return launch_tha<3, 3, DT>(a, w, lds, st);
+    case 4: return launch_tha<4, 4, DT>(a, w, lds, st);
+    case 6: return launch_tha<6, 6, DT>(a, w, lds, st);
+    case 8: return launch_tha<8, 8, DT>(a, w, lds, st);
+    case 16: return launch_tha<16, 8, DT>(a, w, lds, st);
     default: TFIMM_FAIL(TFIMM_EUNSUP, "talking_heads_attention: %d heads not built (1, 2, 3, 4, 6, 8, 16)", a.heads);
   }
 }
@@ -264,7 +332,7 @@ int launch_tha_heads(const ThaArgs& a, size_t lds, hipStream_t st) {
 // reference's miniature test configuration (embed_dim 4, 2 heads); every published CaiT takes the
 // MFMA kernel above.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) tha_generic_kernel(const ThaArgs p, int hd) {
+__global__ void __launch_bounds__(256) tha_generic_kernel(const ThaArgs p, const ThaWeights w, int hd) {
   extern __shared__ float tg[];
   const int H = p.heads, N = p.n;
   float* s0 = tg;                 // [H][N] scores, later mixed probabilities
@@ -283,8 +351,8 @@ __global__ void __launch_bounds__(256) tha_generic_kernel(const ThaArgs p, int h
   __syncthreads();
   for (int id = tid; id < H * N; id += 256) {
     const int hp = id / N, j = id - hp * N;
-    float acc = p.bl[hp];
-    for (int h = 0; h < H; ++h) acc += s0[h * N + j] * p.wl[h * H + hp];
+    float acc = w.bl[hp];
+    for (int h = 0; h < H; ++h) acc += s0[h * N + j] * w.wl[h * H + hp];
     s1[id] = acc;
   }
   __syncthreads();
@@ -307,8 +375,8 @@ __global__ void __launch_bounds__(256) tha_generic_kernel(const ThaArgs p, int h
   __syncthreads();
   for (int id = tid; id < H * N; id += 256) {
     const int hq = id / N, j = id - hq * N;
-    float acc = p.bw[hq];
-    for (int hp = 0; hp < H; ++hp) acc += s1[hp * N + j] * p.ww[hp * H + hq];
+    float acc = w.bw[hq];
+    for (int hp = 0; hp < H; ++hp) acc += s1[hp * N + j] * w.ww[hp * H + hq];
     s0[id] = acc;
   }
   __syncthreads();
@@ -393,11 +461,14 @@ extern "C" int tfimm_hip_talking_heads_attention(const tfimm_tha_desc* dp, void*
     TFIMM_FAIL(TFIMM_EINVAL, "talking_heads_attention: bad shape");
   ThaArgs a;
   a.qkv = (const bf16_t*)d.qkv; a.out = (bf16_t*)d.out;
-  a.wl = d.proj_l_w; a.bl = d.proj_l_b; a.ww = d.proj_w_w; a.bw = d.proj_w_b;
   a.batch = d.batch; a.n = d.n_tokens; a.heads = d.heads; a.scale = d.scale;
   a.dmodel = d.heads * d.hd; a.ld = 3 * a.dmodel;
   a.qchunks = (d.n_tokens + 63) / 64;
-  a.kstr = 0; a.q_in_lds = 0;
+  a.kstr = 0; a.vstr = 0; a.q_in_lds = 0;
+  if (d.heads > 16) TFIMM_FAIL(TFIMM_EUNSUP, "talking_heads_attention: %d heads > 16", d.heads);
+  ThaWeights w;
+  for (int i = 0; i < d.heads * d.heads; ++i) { w.wl[i] = d.proj_l_w[i]; w.ww[i] = d.proj_w_w[i]; }
+  for (int i = 0; i < d.heads; ++i) { w.bl[i] = d.proj_l_b[i]; w.bw[i] = d.proj_w_b[i]; }
   hipStream_t st = (hipStream_t)stream;
   const bool heads_built = d.heads <= 4 || d.heads == 6 || d.heads == 8 || d.heads == 16;
   if ((d.hd != 32 && d.hd != 48) || !heads_built || ((uintptr_t)d.qkv & 15) || ((uintptr_t)d.out & 7)) {
@@ -410,18 +481,21 @@ extern "C" int tfimm_hip_talking_heads_attention(const tfimm_tha_desc* dp, void*
     }
     const int64_t nb = (int64_t)d.batch * d.n_tokens;
     if (nb > 0x7fffffffLL) TFIMM_FAIL(TFIMM_EINVAL, "talking_heads_attention: grid too large");
-    TFIMM_LAUNCH(tha_generic_kernel, dim3((unsigned)nb), dim3(256), lds, st, a, d.hd);
+    TFIMM_LAUNCH(tha_generic_kernel, dim3((unsigned)nb), dim3(256), lds, st, a, w, d.hd);
     return 0;
   }
-  // row stride of the K / Q blocks: >= D + 8 and == 72 (mod 128) elements, i.e. 36 dwords (mod 64 banks):
-  // the 16-row ds_read_b128 fragment reads are then conflict free
-  a.kstr = ((a.dmodel + 8 - 72 + 127) / 128) * 128 + 72;
-  const size_t base = (size_t)THA_KB * a.kstr * 2 + (size_t)a.dmodel * THA_VSTR * 2 + (size_t)4 * d.heads * 16 * 2 * 4;
+  // row strides: >= row length + 8 and == 72 (mod 128) elements, i.e. 36 dwords (mod 64 banks), which keeps
+  // the 16-row ds_read_b128 fragment reads conflict free
+  const int hp_ = (d.hd + 31) / 32 * 32;
+  a.kstr = ((d.heads * hp_ + 8 - 72 + 127) / 128) * 128 + 72;
+  a.vstr = ((a.dmodel + 8 - 72 + 127) / 128) * 128 + 72;
+  const size_t base = (size_t)THA_KB * a.kstr * 2 + (size_t)THA_KB * a.vstr * 2 + (size_t)4 * d.heads * 16 * 2 * 4 +
+                      (size_t)((2 * (d.heads * d.heads + d.heads) + 3) / 4 * 4) * 4;
   const size_t qbytes = (size_t)64 * a.kstr * 2;
   a.q_in_lds = (base + qbytes <= 160 * 1024) ? 1 : 0;   // else Q fragments are re-read from L1/L2 per key tile
   const size_t lds = base + (a.q_in_lds ? qbytes : 0);
   if (lds > 160 * 1024) TFIMM_FAIL(TFIMM_EUNSUP, "talking_heads_attention: embed dim %d needs %zu bytes of LDS", a.dmodel, lds);
-  return d.hd == 32 ? launch_tha_heads<2>(a, lds, st) : launch_tha_heads<3>(a, lds, st);
+  return d.hd == 32 ? launch_tha_heads<2>(a, w, lds, st) : launch_tha_heads<3>(a, w, lds, st);
 }
 
 extern "C" int tfimm_hip_class_attention(const void* q, const void* kv, void* out, int B, int n_tokens, int heads,

@@ -679,8 +679,11 @@ class Plan:
                 d = ffi.ThaDesc()
                 d.qkv = self.tptr(op.inputs[0])
                 d.out = self.tptr(op.output)
-                d.proj_l_w, d.proj_l_b = self.cptr(op.consts["wl"]), self.cptr(op.consts["bl"])
-                d.proj_w_w, d.proj_w_b = self.cptr(op.consts["ww"]), self.cptr(op.consts["bw"])
+                # the head-mixing layers go by HOST pointer (copied into the kernel arguments at launch)
+                host = {r: prog.consts[op.consts[r]].host for r in ("wl", "bl", "ww", "bw")}
+                self._keepalive.append(host)
+                d.proj_l_w, d.proj_l_b = host["wl"].ctypes.data, host["bl"].ctypes.data
+                d.proj_w_w, d.proj_w_b = host["ww"].ctypes.data, host["bw"].ctypes.data
                 d.batch, d.n_tokens, d.heads, d.hd, d.scale = B, a["n_tokens"], a["heads"], a["hd"], a["scale"]
                 self._keepalive.append(d)
                 self.calls.append((lib.tfimm_hip_talking_heads_attention, (C.byref(d),)))

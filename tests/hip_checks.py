@@ -345,8 +345,7 @@ def _tha_case(B, N, heads, hd, seed):
     bw = (0.02 * r.standard_normal(heads)).astype(np.float32)
     scale = hd ** -0.5
     ref = _tha_ref(qkv, B, N, heads, hd, scale, wl, bl, ww, bw)
-    got = H.talking_heads_attention(H.dev_bf16(qkv), B, N, heads, hd, scale, H.dev_f32(wl), H.dev_f32(bl),
-                                    H.dev_f32(ww), H.dev_f32(bw))
+    got = H.talking_heads_attention(H.dev_bf16(qkv), B, N, heads, hd, scale, wl, bl, ww, bw)
     H.sync()
     return _err(_cpu(got), ref), 1.5e-2   # mixed probabilities are rounded to bf16 before P.V
 

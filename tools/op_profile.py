@@ -34,6 +34,10 @@ def op_bytes_flops(op, prog, B):
         return byts, 2.0 * M * N * K, f"M={M} K={a['K']} N={N} mode={a['mode']}" + \
             (f" {a['KH']}x{a['KW']}s{a['stride']} {a['H']}->{a['OH']}" if a["mode"] else "") + \
             (" +res" if a.get("has_residual") else "") + (f" {a['act']}" if a["act"] else "")
+    if k == "talking_heads_attention":
+        rows = B * a["n_tokens"]
+        d = a["heads"] * a["hd"]
+        return rows * d * 2 * 4, float(a["flops"]) * B, f"rows={rows} heads={a['heads']} hd={a['hd']} talking-heads"
     if k == "attention":
         rows = B * a["n_tokens"]
         d = a["heads"] * a["hd"]
