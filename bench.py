@@ -31,6 +31,8 @@ WORKLOADS = {
     "swin_base_patch4_window7_224": dict(model="swin_base_patch4_window7_224", batch=256, bound="hbm"),
     "efficientnet_b4": dict(model="efficientnet_b4", batch=256, bound="hbm"),
     "vit_tiny_patch16_224": dict(model="vit_tiny_patch16_224", batch=1, bound="mfma"),
+    "convnext_tiny": dict(model="convnext_tiny", batch=256, bound="hbm"),
+    "cait_xxs24_224": dict(model="cait_xxs24_224", batch=256, bound="mfma"),
 }
 PEAK = {"hbm": (8000.0, "GB/s"), "mfma": (2500.0, "TFLOP/s")}   # MI355X_MICROARCH.md chip table
 # algorithmic activation bytes per image (bf16, conv/linear outputs written once + read once,

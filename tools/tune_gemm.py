@@ -14,7 +14,8 @@ for p in (ROOT, os.path.join(ROOT, "tensorflow-image-models_amd"), os.path.join(
 import torch  # noqa: E402,F401
 
 DEFAULT = ["resnet50:256", "vit_base_patch16_224:512", "swin_base_patch4_window7_224:256", "efficientnet_b4:256",
-           "vit_tiny_patch16_224:1", "vit_tiny_patch16_224:2", "resnet50:8", "resnet50:2"]
+           "convnext_tiny:256", "cait_xxs24_224:256", "vit_tiny_patch16_224:1", "vit_tiny_patch16_224:2", "resnet50:8",
+           "resnet50:2"]
 
 
 def main():
