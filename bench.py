@@ -57,6 +57,18 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(workload, batch):
+    """HBM bytes per GEMM-family launch from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE / WRITE_SIZE cannot be collected from inside this process): tools/gpu_traffic.sh.
+    None when no profile of this workload / batch exists."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if workload != "resnet50" or batch != 256 or not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        t = json.load(f)
+    return round(t["gemm_hbm_bytes_per_launch"]), "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+
+
 def build_model(name):
     import tfimm
     from tfimm.utils.init import synthetic_weights
@@ -263,8 +275,12 @@ def main():
                 # the only producers/consumers under the §8d convention) + weights once per launch set
                 alg = ALG_BYTES_PER_IMAGE.get(args.workload, 0.0) * batch + prog.weight_bytes()
                 achieved = alg * args.steps / (gk["ms"] * 1e-3) / 1e9
+            traffic, traffic_src = measured_traffic(args.workload, batch)
             roof = dict(bound=bound, achieved=round(achieved, 2), peak=peak, unit=punit,
-                        frac=round(achieved / peak, 4), traffic=None, kernel="tfimm_gemm::gemm_kernel (all flavours)",
+                        frac=round(achieved / peak, 4), traffic=traffic, traffic_unit="HBM bytes per launch (PMC)",
+                        traffic_source=traffic_src, algorithmic_bytes_per_launch=(
+                            None if bound == "mfma" else round(alg / launches_per_step)),
+                        kernel="tfimm_gemm::gemm_kernel (all flavours)",
                         launches_per_step=launches_per_step, avg_launch_ms=round(avg_ms, 5),
                         share_of_step=round(gk["ms"] / args.steps / ms, 3),
                         timing="HIP event pair around every launch, on the launch stream, over K eagerly launched "

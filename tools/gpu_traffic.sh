@@ -1,0 +1,30 @@
+#!/bin/bash
+# HBM traffic of the bench workload from rocprofv3 PMC counters (MI355X_MICROARCH.md §HBM): FETCH_SIZE and
+# WRITE_SIZE in separate --pmc passes over an eager (no hipGraph) run of bench.py; per-kernel sums per step
+# go to gpurun_out/traffic.json.  Kernels with known byte counts (input cast, maxpool) calibrate the units.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp; cd /tmp
+STEPS=3; WARM=1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/traffic_$c -o t -- python $R/bench.py --steps $STEPS --warmup $WARM --no-graph --no-cpu-baseline --no-kernel-events --extra "" > $O/traffic_$c.log 2>&1
+  echo "$c rc=$?"
+done
+python - "$O" $STEPS $WARM <<'PY'
+import csv, glob, json, sys, collections
+O, steps, warm = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+out = {"steps_profiled": steps + warm}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(f"{O}/traffic_{c}/**/*counter_collection.csv", recursive=True)
+    if not f:
+        continue
+    agg = collections.defaultdict(float); cnt = collections.Counter()
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] != c:
+            continue
+        k = r["Kernel_Name"]
+        fam = "gemm" if "tfimm_gemm" in k else ("maxpool" if "maxpool" in k else ("cast_input" if "cast" in k else ("mean_rows" if "mean_rows" in k else "other")))
+        agg[fam] += float(r["Counter_Value"]); cnt[fam] += 1
+    out[c] = {k: {"sum": v, "dispatches": cnt[k]} for k, v in agg.items()}
+json.dump(out, open(f"{O}/traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY
