@@ -58,8 +58,12 @@ def cait_forward(cfg, weights, x, return_features=False):
     feats = OrderedDict()
     B = x.shape[0]
     x = ops.conv2d(x, w("patch_embed/proj/kernel"), w("patch_embed/proj/bias"), stride=cfg.patch_size)
+    grid = (x.shape[1], x.shape[2])
     x = x.reshape(B, -1, x.shape[-1])                                 # transformers.py:167-170
-    x = x + w("pos_embed")                                            # cait.py:406
+    pos = w("pos_embed")
+    if cfg.interpolate_input:                                         # cait.py:407-415
+        pos = ops.interpolate_pos_embeddings(pos, cfg.grid_size, grid, 0)
+    x = x + pos                                                       # cait.py:406
     feats["patch_embedding"] = x
     for j in range(cfg.nb_blocks):                                    # :417-419, LayerScaleBlock.call :311-326
         p = f"blocks/{j}"

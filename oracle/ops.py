@@ -156,3 +156,58 @@ def global_avg_pool(x: T) -> T:
 def roll(x: T, shift: Sequence[int], axis: Sequence[int]) -> T:
     """tf.roll: out[i] = in[(i - shift) mod n]  (swin.py:299,313)."""
     return torch.roll(x, shifts=tuple(shift), dims=tuple(axis))
+
+
+# ---- image resize -----------------------------------------------------------------------------
+def resize_bicubic_tf(x: T, size: Tuple[int, int]) -> T:
+    """tf.image.resize(method="bicubic", antialias=False) on NHWC (layers/transformers.py:38-42),
+    restated tap by tap from TensorFlow's resize_bicubic_op (half-pixel centres; Keys kernel A = -0.5
+    read from a 1024-entry table at the ROUNDED fractional offset; taps outside the image weigh 0 and
+    the rest are renormalised).  Deliberately written as plain loops, independently of the engine's
+    vectorised host version (tfimm/layers/transformers.py)."""
+    A = -0.5
+    TAB = 1024
+
+    def near(i):
+        t = np.float32(i) / np.float32(TAB)
+        return np.float32(((A + 2) * t - (A + 3)) * t * t + 1)
+
+    def far(i):
+        t = np.float32(i) / np.float32(TAB) + np.float32(1)
+        return np.float32(((A * t - 5 * A) * t + 8 * A) * t - 4 * A)
+
+    def taps(n_in, n_out):
+        out = []
+        scale = np.float32(n_in) / np.float32(n_out)
+        for o in range(n_out):
+            loc = (np.float32(o) + np.float32(0.5)) * scale - np.float32(0.5)
+            base = math.floor(float(loc))
+            off = int(np.rint((loc - np.float32(base)) * TAB))
+            cand = [(base - 1, far(off)), (base, near(off)), (base + 1, near(TAB - off)), (base + 2, far(TAB - off))]
+            kept = [(i, w) for i, w in cand if 0 <= i < n_in]
+            tot = sum(w for _, w in kept)
+            out.append([(i, np.float32(w / tot)) for i, w in kept])
+        return out
+
+    x = as_t(x)
+    B, H, W, C = x.shape
+    ty, tx = taps(H, size[0]), taps(W, size[1])
+    rows = torch.zeros(B, size[0], W, C)
+    for oy, tl in enumerate(ty):
+        for i, w in tl:
+            rows[:, oy] += float(w) * x[:, i]
+    out = torch.zeros(B, size[0], size[1], C)
+    for ox, tl in enumerate(tx):
+        for i, w in tl:
+            out[:, :, ox] += float(w) * rows[:, :, i]
+    return out
+
+
+def interpolate_pos_embeddings(pos_embed: T, src_grid, tgt_grid, nb_tokens: int = 0) -> T:
+    """layers/transformers.py:13-47."""
+    pos_embed = as_t(pos_embed)
+    if tuple(src_grid) == tuple(tgt_grid):
+        return pos_embed
+    g = pos_embed[:, nb_tokens:].reshape(1, src_grid[0], src_grid[1], -1)
+    g = resize_bicubic_tf(g, tgt_grid).reshape(1, tgt_grid[0] * tgt_grid[1], -1)
+    return torch.cat((pos_embed[:, :nb_tokens], g), dim=1)

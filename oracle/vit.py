@@ -34,6 +34,7 @@ def vit_forward(cfg, weights, x, return_features=False):
     B = x.shape[0]
     # PatchEmbeddings: ZeroPadding2D(0) -> Conv2D(k=s=patch, bias) -> flatten -> norm("") identity
     x = ops.conv2d(x, w("patch_embed/proj/kernel"), w("patch_embed/proj/bias"), stride=cfg.patch_size)
+    _grid = (x.shape[1], x.shape[2])                                  # return_shape=True, transformers.py:171-172
     x = x.reshape(B, -1, x.shape[-1])                                 # transformers.py:167-170
     cls = w("cls_token").expand(B, -1, -1)                            # vit.py:427 tf.repeat
     if not cfg.distilled:
@@ -41,7 +42,11 @@ def vit_forward(cfg, weights, x, return_features=False):
     else:
         dist = w("dist_token").expand(B, -1, -1)
         x = torch.cat((cls, dist, x), dim=1)                          # :431-432
-    x = x + w("pos_embed")                                            # :434
+    pos = w("pos_embed")
+    if cfg.interpolate_input:                                         # :433-442
+        grid = _grid
+        pos = ops.interpolate_pos_embeddings(pos, cfg.grid_size, grid, cfg.nb_tokens)
+    x = x + pos                                                       # :434
     feats["patch_embedding"] = x
     for j in range(cfg.nb_blocks):
         p = f"blocks/{j}"

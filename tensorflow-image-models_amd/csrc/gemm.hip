@@ -15,6 +15,7 @@ TFIMM_GEMM_DMA_TILES(TFIMM_DECL)
 #define TFIMM_DECL(ID, BM_, BN_, WM_, WN_) extern "C" const StreamTileCfg tfimm_gemm_stream_tile_##ID;
 TFIMM_GEMM_STREAM_TILES(TFIMM_DECL)
 #undef TFIMM_DECL
+extern "C" const StreamTileCfg tfimm_gemm_stream_tile_7;
 
 namespace {
 
@@ -43,6 +44,7 @@ const StreamTileCfg* stream_tile_table(int i) {
   case ID: return &tfimm_gemm_stream_tile_##ID;
   switch (i) {
     TFIMM_GEMM_STREAM_TILES(TFIMM_CASE)
+    case 7: return &tfimm_gemm_stream_tile_7;
     default: return nullptr;
   }
 #undef TFIMM_CASE
@@ -107,7 +109,7 @@ int pick_dma_tile(const tfimm_gemm_desc& d) {
 // ceil(tiles / slots) rounds; score = efficiency x useful area x fill of those rounds.
 int pick_stream_tile(const tfimm_gemm_desc& d, const int* occ) {
   if (d.tile_hint > 20 && d.tile_hint <= 20 + TFIMM_GEMM_STREAM_NUM_TILES) return d.tile_hint - 21;
-  static const double eff[TFIMM_GEMM_STREAM_NUM_TILES] = {1.00, 0.90, 0.75, 0.70, 0.55, 0.90, 0.75};
+  static const double eff[TFIMM_GEMM_STREAM_NUM_TILES] = {1.00, 0.90, 0.75, 0.70, 0.55, 0.90, 0.75, 0.0};
   const int cus = num_cu();
   int best = 2;
   double best_score = -1.0;

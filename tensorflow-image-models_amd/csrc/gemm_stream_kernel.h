@@ -473,4 +473,5 @@ struct StreamTileCfg {
   X(4, 128, 64, 2, 2)              \
   X(5, 128, 256, 2, 4)             \
   X(6, 256, 64, 4, 1)
-#define TFIMM_GEMM_STREAM_NUM_TILES 7
+// id 7 = the 256x256 deep-ring schedule (gemm_pipe_kernel.h), instantiated on its own
+#define TFIMM_GEMM_STREAM_NUM_TILES 8

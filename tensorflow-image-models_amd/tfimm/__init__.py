@@ -4,7 +4,7 @@ Drop-in for the inference path of martinsbruveris/tensorflow-image-models:
 ``tfimm.create_model(name)(x)``, ``tfimm.list_models()``, ``tfimm.create_preprocessing()``
 (reference tfimm/__init__.py:1-12).  Importing the package registers all architectures.
 """
-from . import architectures  # noqa: F401
+from . import architectures, layers  # noqa: F401
 from .models.factory import create_model, create_preprocessing  # noqa: F401
 from .models.registry import list_models  # noqa: F401
 from .utils import (  # noqa: F401

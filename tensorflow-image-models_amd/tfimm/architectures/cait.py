@@ -23,6 +23,7 @@ from typing import List, Tuple
 
 import numpy as np
 
+from ..layers.transformers import interpolate_pos_embeddings
 from ..models.config import ModelConfig
 from ..models.model import Model, WeightSpec
 from ..models.registry import register_model
@@ -132,6 +133,14 @@ class CaiT(Model):
         return s
 
     @property
+    def transform_weights(self):
+        """cait.py:91-93, 386-392: position embeddings follow the target's patch grid (no token rows)."""
+        return {"pos_embed": CaiT.transform_pos_embed}
+
+    def transform_pos_embed(self, src_weights, target_cfg):
+        return interpolate_pos_embeddings(src_weights, self.cfg.grid_size, target_cfg.grid_size, 0)
+
+    @property
     def feature_names(self) -> List[str]:
         c = self.cfg
         return (["patch_embedding"] + [f"block_{j}" for j in range(c.nb_blocks)] + ["features_cls_token"]
@@ -140,17 +149,21 @@ class CaiT(Model):
     # -- lowering ------------------------------------------------------------------------------------
     def lower(self, b, H, W, want_features):
         c = self.cfg
+        grid = (H // c.patch_size, W // c.patch_size)
+        pos = b.wget("pos_embed")
         if (H, W) != tuple(c.input_size):
-            raise NotImplementedError(
-                "CaiT inference at a non-native input size needs interpolate_input (pos-embed bicubic "
-                "resize, layers/transformers.py:13-47): not built yet.")
+            if not c.interpolate_input:
+                raise ValueError(
+                    f"{c.name} was built for {c.input_size} inputs; got {(H, W)}. Create the model with "
+                    "interpolate_input=True to resize the position embeddings (cait.py:407-415).")
+            pos = interpolate_pos_embeddings(pos, c.grid_size, grid, 0)   # the class token has no position
         eps = _LN_EPS[c.norm_layer]
-        D, nh, N = c.embed_dim, c.nb_heads, c.nb_patches
+        D, nh, N = c.embed_dim, c.nb_heads, grid[0] * grid[1]
         scale = (D // nh) ** -0.5
         from ..engine.pack import to_bf16_bits
 
         x = b.image_input(H, W, c.in_channels)
-        pos_const = b.p.new_const(np.ascontiguousarray(to_bf16_bits(b.wget("pos_embed")[0])), "pos_embed")
+        pos_const = b.p.new_const(np.ascontiguousarray(to_bf16_bits(pos[0])), "pos_embed")
         x = b.conv(x, "patch_embed/proj/kernel", stride=c.patch_size, padding=0, bias="patch_embed/proj/bias",
                    flatten=True, res_const=pos_const, res_mod=N,
                    cite="layers/transformers.py:164-170 + cait.py:404-413", name="tokens")

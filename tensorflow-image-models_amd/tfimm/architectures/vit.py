@@ -17,6 +17,7 @@ from typing import List, Optional, Tuple, Union
 
 import numpy as np
 
+from ..layers.transformers import interpolate_pos_embeddings
 from ..models.config import ModelConfig
 from ..models.model import Model, WeightSpec
 from ..models.registry import register_model
@@ -132,6 +133,15 @@ class ViT(Model):
         return s
 
     @property
+    def transform_weights(self):
+        """Per-weight adaptations ``transfer_weights`` applies when source and target configs differ
+        (vit.py:117-119, 414-420): position embeddings are resized to the target's patch grid."""
+        return {"pos_embed": ViT.transform_pos_embed}
+
+    def transform_pos_embed(self, src_weights, target_cfg):
+        return interpolate_pos_embeddings(src_weights, self.cfg.grid_size, target_cfg.grid_size, self.cfg.nb_tokens)
+
+    @property
     def feature_names(self) -> List[str]:
         names = ["patch_embedding"]
         for j in range(self.cfg.nb_blocks):
@@ -141,14 +151,19 @@ class ViT(Model):
     # -- lowering ------------------------------------------------------------------------------------
     def lower(self, b, H, W, want_features):
         c = self.cfg
+        grid = (H // c.patch_size, W // c.patch_size)
+        pos = b.wget("pos_embed")
         if (H, W) != tuple(c.input_size):
-            raise NotImplementedError(
-                "ViT inference at a non-native input size needs interpolate_input (pos-embed "
-                "bicubic resize, layers/transformers.py:13-47): not built yet.")
+            if not c.interpolate_input:
+                raise ValueError(
+                    f"{c.name} was built for {c.input_size} inputs; got {(H, W)}. Create the model with "
+                    "interpolate_input=True to resize the position embeddings (vit.py:433-442).")
+            # bicubic resize of the patch-grid embeddings, once per input size, on the host (vit.py:436-441)
+            pos = interpolate_pos_embeddings(pos, c.grid_size, grid, c.nb_tokens)
         eps = _LN_EPS[c.norm_layer]
-        D, nh, nt, npatch = c.embed_dim, c.nb_heads, c.nb_tokens, c.nb_patches
+        D, nh, nt, npatch = c.embed_dim, c.nb_heads, c.nb_tokens, grid[0] * grid[1]
         N = npatch + nt
-        pos = b.wget("pos_embed")[0]                               # (N, D)
+        pos = pos[0]                                               # (N, D)
         x = b.image_input(H, W, c.in_channels)
         # patch conv -> token rows [nt, N), + pos_embed[nt:] in the epilogue
         pos_const = b.p.new_const(np.ascontiguousarray(_bf16_bits(pos[nt:])), "pos_embed[patches]")

@@ -94,15 +94,16 @@ def _gemm_case(M, K, N, *, act="", bias=True, residual=False, act_after_res=Fals
     return _err(got, ref), (TOL_F32 if out_f32 else TOL_BF16)
 
 
-# tile hints: 0 auto, 1..6 register-staged tiles, 11..16 LDS-DMA tiles, 21..27 persistent LDS-DMA tiles
-for _t in list(range(0, 7)) + list(range(11, 17)) + list(range(21, 28)):
+# tile hints: 0 auto, 1..6 register-staged tiles, 11..16 LDS-DMA tiles, 21..27 persistent LDS-DMA tiles,
+# 28 the 256x256 deep-ring schedule
+for _t in list(range(0, 7)) + list(range(11, 17)) + list(range(21, 29)):
     CASES[f"gemm_tile{_t:02d}_256x192x320"] = (lambda t=_t: _gemm_case(256, 192, 320, tile=t, seed=1))
     CASES[f"gemm_tile{_t:02d}_ragged_333x200x150_gelu_res"] = (
         lambda t=_t: _gemm_case(333, 200, 150, act="gelu", residual=True, tile=t, seed=2))
     CASES[f"gemm_tile{_t:02d}_600x320x520_relu_after_res_f32"] = (
         lambda t=_t: _gemm_case(600, 320, 520, act="relu", residual=True, act_after_res=True, out_f32=True, tile=t,
                                 seed=3))
-for _t in range(21, 28):
+for _t in range(21, 29):
     # more tiles than resident workgroups: every persistent workgroup walks several tiles (ragged M, N, K)
     CASES[f"gemm_stream_multiround_tile{_t:02d}"] = (
         lambda t=_t: _gemm_case(40000, 200, 520, act="gelu", residual=True, tile=t, seed=50 + t))
@@ -219,7 +220,7 @@ CASES["conv3x3_s2_same_even"] = lambda: _conv_case(2, 20, 20, 16, 24, 3, 2, "sam
 CASES["conv3x3_scalar_cin6"] = lambda: _conv_case(2, 8, 8, 6, 10, 3, 1, 1, act="relu", seed=39)
 CASES["conv3x3_scalar_cin2_s2"] = lambda: _conv_case(3, 9, 9, 2, 4, 3, 2, 1, seed=40)
 CASES["conv1ch_8x8_patch"] = lambda: _conv_case(2, 32, 32, 1, 4, 8, 8, 0, bn=False, seed=41)
-for _t in (1, 2, 3, 4, 5, 6, 11, 12, 13, 14, 15, 16, 21, 22, 23, 24, 25, 26, 27):
+for _t in (1, 2, 3, 4, 5, 6, 11, 12, 13, 14, 15, 16, 21, 22, 23, 24, 25, 26, 27, 28):
     CASES[f"conv3x3_tile{_t:02d}"] = (lambda t=_t: _conv_case(2, 16, 16, 64, 96, 3, 1, 1, act="relu", seed=42, tile=t))
     CASES[f"conv3x3_s2_res_tile{_t:02d}"] = (
         lambda t=_t: _conv_case(3, 15, 13, 40, 72, 3, 2, 1, act="relu", residual=True, seed=43, tile=t))
@@ -232,17 +233,23 @@ CASES["pair_conv4x4_s4_rgb_patch"] = lambda: _conv_case(2, 32, 32, 3, 128, 4, 4,
 CASES["pair_conv3x3_s2_same_rgb_odd"] = lambda: _conv_case(2, 33, 33, 3, 48, 3, 2, "same", act="swish", seed=137, pair=True)
 CASES["pair_conv3x3_s2_same_rgb_380"] = lambda: _conv_case(1, 380, 380, 3, 48, 3, 2, "same", act="swish", seed=140, pair=True)
 CASES["pair_conv1ch_8x8_patch"] = lambda: _conv_case(2, 32, 32, 1, 8, 8, 8, 0, bn=False, seed=138, pair=True)
-for _t in (21, 24):
+for _t in (21, 24, 28):
     CASES[f"conv3x3_stream_multiround_tile{_t:02d}"] = (
         lambda t=_t: _conv_case(32, 56, 56, 64, 64, 3, 1, 1, act="relu", residual=True, seed=70 + t, tile=t))
 # 256x256 persistent tile: deep K (many k-tiles per tile, several tiles per workgroup), K tail, two k-tiles
-CASES["gemm_t21_deepk_3000x1600x520"] = lambda: _gemm_case(3000, 1600, 520, act="gelu", residual=True, tile=21, seed=91)
-CASES["gemm_t21_two_ktiles_70000x128x512"] = lambda: _gemm_case(70000, 128, 512, tile=21, seed=92)
-CASES["gemm_t21_ktail_5000x200x256"] = lambda: _gemm_case(5000, 200, 256, act="relu", tile=21, seed=93)
+CASES["gemm_t21_deepk_3000x1600x520"] = lambda: _gemm_case(3000, 1600, 520, act="gelu", residual=True, tile=28, seed=91)
+CASES["gemm_t21_two_ktiles_70000x128x512"] = lambda: _gemm_case(70000, 128, 512, tile=28, seed=92)
+CASES["gemm_t21_ktail_5000x200x256"] = lambda: _gemm_case(5000, 200, 256, act="relu", tile=28, seed=93)
 CASES["gemm_t21_resmod_remap_19600x192x768"] = lambda: _gemm_case(19600, 192, 768, residual=True, res_mod=196,
                                                                  remap=(196, 197, 1), tile=21, seed=96)
 CASES["conv3x3_t21_cin128_multiround"] = lambda: _conv_case(24, 28, 28, 128, 256, 3, 1, 1, act="relu", residual=True, seed=94, tile=21)
 CASES["conv3x3_t21_cin40_s2"] = lambda: _conv_case(16, 31, 29, 40, 264, 3, 2, 1, act="relu", seed=95, tile=21)
+for _t in (21, 28):
+    CASES[f"gemm_t{_t}_resmod_remap_19600x200x768"] = (
+        lambda t=_t: _gemm_case(19600, 200, 768, residual=True, res_mod=196, remap=(196, 197, 1), tile=t, seed=97))
+    CASES[f"conv3x3_t{_t}_cin40_s2_ragged"] = (
+        lambda t=_t: _conv_case(16, 31, 29, 40, 264, 3, 2, 1, act="relu", residual=True, seed=98, tile=t))
+    CASES[f"gemm_t{_t}_k32_single_ktile"] = (lambda t=_t: _gemm_case(9000, 32, 520, act="relu", tile=t, seed=99))
 CASES["conv3x3_cin128_tapstep"] = lambda: _conv_case(4, 14, 14, 128, 96, 3, 1, 1, act="relu", seed=75)
 CASES["conv3x3_s2_cin192_tapstep"] = lambda: _conv_case(3, 15, 15, 192, 64, 3, 2, 1, seed=76)
 CASES["conv1x1_s2_cin64_stream"] = lambda: _conv_case(2, 28, 28, 64, 128, 1, 2, 0, seed=77, tile=23)

@@ -59,6 +59,14 @@ def test_cait_features_and_reference_mini():
     assert r["logits"] <= 2 * mc.TOL_LOGITS, r
 
 
+@pytest.mark.parametrize("name,size", [("vit_hd64_test_model", (80, 48)), ("cait_hd48_test_model", (48, 96)),
+                                       ("vit_tiny_patch16_224", (160, 256))])
+def test_interpolate_input(name, size):
+    """ViT / CaiT at a non-native input size: position embeddings resized on the host (vit.py:433-442)."""
+    r = mc.compare_model(name, batch=2, size=size, interpolate_input=True)
+    assert r["logits"] <= mc.TOL_LOGITS, r
+
+
 def test_micro_batch_equals_full_batch():
     import tfimm
     from tfimm.utils.init import synthetic_weights
