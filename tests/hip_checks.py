@@ -596,12 +596,10 @@ def _():
     return max(_err(_cpu(g), gate), _err(_cpu(y), ref_y)), TOL_BF16
 
 
-@case("patch_merge_ln")
-def _():
+def _patch_merge_case(B, Hh, Ww, Cc, seed):
     import hip_ops as H
-    r = _rng(97)
-    B, Hh, Ww, Cc = 2, 6, 8, 16
-    x = _bf(r.standard_normal((B, Hh * Ww, Cc)))
+    r = _rng(seed)
+    x = _bf(r.standard_normal((B, Hh * Ww, Cc)) + 0.5)
     g = r.uniform(0.5, 1.5, 4 * Cc).astype(np.float32)
     b = r.standard_normal(4 * Cc).astype(np.float32)
     t = torch.from_numpy(x).reshape(B, Hh, Ww, Cc)
@@ -610,6 +608,14 @@ def _():
     got = H.patch_merge_ln(H.dev_bf16(x), H.dev_f32(g), H.dev_f32(b), Hh, Ww, 1e-5)
     H.sync()
     return _err(_cpu(got), ref), TOL_BF16
+
+
+CASES["patch_merge_ln"] = lambda: _patch_merge_case(2, 6, 8, 16, 97)            # one partial chunk set (64 of 64 lanes: 8 chunks)
+CASES["patch_merge_ln_c128_swin_stage1"] = lambda: _patch_merge_case(2, 14, 14, 128, 98)   # 1 chunk per lane
+CASES["patch_merge_ln_c192"] = lambda: _patch_merge_case(1, 4, 6, 192, 99)        # 96 chunks: 2 per lane, half masked
+CASES["patch_merge_ln_c512"] = lambda: _patch_merge_case(1, 4, 4, 512, 100)       # 4 chunks per lane
+CASES["patch_merge_ln_c1024"] = lambda: _patch_merge_case(1, 2, 2, 1024, 101)     # 8 chunks per lane
+CASES["patch_merge_ln_c12_scalar"] = lambda: _patch_merge_case(2, 4, 4, 12, 102)  # C % 8 != 0: element-wise kernel
 
 
 def run_case(name):

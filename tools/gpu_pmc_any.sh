@@ -14,10 +14,10 @@ import csv,sys,collections
 rows=list(csv.DictReader(open(sys.argv[1])))
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
 for r in rows:
-    k=r.get("Kernel_Name","")[:50]
+    k=r.get("Kernel_Name","")[:50].replace("void (anonymous namespace)::","")
     if sys.argv[2] not in r.get("Kernel_Name",""): continue
     agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[(k,r["Counter_Name"])]+=1
 for k,v in agg.items():
-    for c,val in v.items(): print(f"{k:50s} {c:28s} {val/cnt[(k,c)]:.4g}")
+    for c,val in v.items(): print(f"{k:42s} {c:26s} {val/cnt[(k,c)]:.4g}")
 PY
 done
