@@ -275,6 +275,11 @@ CASES["layernorm_192"] = lambda: _ln_case(50, 192, 1e-6, 51)
 CASES["layernorm_1024"] = lambda: _ln_case(33, 1024, 1e-5, 52)
 CASES["layernorm_2048"] = lambda: _ln_case(9, 2048, 1e-5, 53)
 CASES["layernorm_4096"] = lambda: _ln_case(5, 4096, 1e-5, 54)
+CASES["layernorm_narrow_128_rows_tail"] = lambda: _ln_case(1003, 128, 1e-5, 57)   # 4 rows per wave, 1003 % 4 != 0
+CASES["layernorm_narrow_96"] = lambda: _ln_case(61, 96, 1e-6, 58)                 # 12 of 16 lanes per row
+CASES["layernorm_narrow_256"] = lambda: _ln_case(77, 256, 1e-5, 59)               # 2 rows per wave
+CASES["layernorm_narrow_64"] = lambda: _ln_case(131, 64, 1e-6, 60)                # 8 rows per wave
+CASES["layernorm_narrow_16"] = lambda: _ln_case(19, 16, 1e-6, 61)                 # 2 of 8 lanes per row
 CASES["layernorm_generic_d4"] = lambda: _ln_case(34, 4, 1e-6, 55)
 CASES["layernorm_generic_d100"] = lambda: _ln_case(7, 100, 1e-5, 56)
 
