@@ -259,7 +259,8 @@ TFIMM_API int tfimm_hip_dwconv(const void* x, const float* w, const float* bias,
 
 /* ---------------------------------------------------------------------------------------
  * tfimm_hip_se_gate: gate[b][c] = gate_act( W2 . act( W1 . mean[b] + b1 ) + b2 )[c]
- * with mean[b][c] = sums[b][c] * inv_count.  w1: fp32 [rd][C], w2: fp32 [C][rd].
+ * with mean[b][c] = sums[b][c] * inv_count.  w1: fp32 [rd][C] (reduce conv, transposed), w2: fp32 [rd][C]
+ * (expand conv as Keras stores it) -- both are walked along C by consecutive threads.
  * SqueezeExcite.call (efficientnet_blocks.py:241-248) / SEModule.call (layers/attention.py:66-74)
  * minus the final multiply, which is fused into the consumer (a_scale of tfimm_hip_gemm)
  * or done by tfimm_hip_scale_channels.

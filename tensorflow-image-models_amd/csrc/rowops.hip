@@ -942,29 +942,56 @@ static int launch_dwconv_strip(const bf16_t* x, const float* w, const float* bia
 // ---------------------------------------------------------------------------------------
 // SE gate: one block per image
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) se_gate_kernel(const float* sums, float inv_count, const float* w1,
-                                                      const float* b1, const float* w2, const float* b2,
-                                                      float* gate, int C, int rd, int act, int gate_act) {
-  extern __shared__ float sm[];  // [C] means + [rd] hidden
+// One 1024-thread workgroup per image (the kernel is latency-bound: 16 waves share the rd reduction rows; packing 4
+// images into a workgroup to reuse the weights measured 1.5x SLOWER).  w1 rows are read by whole waves and w2
+// ([rd][C]: the Keras layout of the expand conv) by consecutive threads -- all loads coalesced.  (256 threads and a
+// [C][rd] w2 walked row-per-thread took 67 us for C = 1632.)
+constexpr int SE_IMG = 1;
+__global__ void __launch_bounds__(1024) se_gate_kernel(const float* __restrict__ sums, float inv_count,
+                                                      const float* __restrict__ w1, const float* __restrict__ b1,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2,
+                                                      float* __restrict__ gate, int B, int C, int rd, int act,
+                                                      int gate_act) {
+  extern __shared__ float sm[];  // [SE_IMG][C] means + [SE_IMG][rd] hidden
   float* mean = sm;
-  float* hid = sm + C;
-  const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) mean[c] = sums[(int64_t)b * C + c] * inv_count;
+  float* hid = sm + SE_IMG * C;
+  const int b0 = blockIdx.x * SE_IMG;
+  for (int i = threadIdx.x; i < SE_IMG * C; i += blockDim.x) {
+    const int im = i / C;
+    mean[i] = b0 + im < B ? sums[(int64_t)b0 * C + i] * inv_count : 0.f;
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int j = wave; j < rd; j += nw) {
-    float s = 0.f;
+    float s[SE_IMG];
+#pragma unroll
+    for (int im = 0; im < SE_IMG; ++im) s[im] = 0.f;
     const float* wr = w1 + (int64_t)j * C;
-    for (int c = lane; c < C; c += 64) s += wr[c] * mean[c];
-    s = wave_sum(s);
-    if (lane == 0) hid[j] = apply_act(s + (b1 ? b1[j] : 0.f), act);
+    for (int c = lane; c < C; c += 64) {
+      const float wv = wr[c];
+#pragma unroll
+      for (int im = 0; im < SE_IMG; ++im) s[im] += wv * mean[im * C + c];
+    }
+#pragma unroll
+    for (int im = 0; im < SE_IMG; ++im) {
+      const float t = wave_sum(s[im]);
+      if (lane == 0) hid[im * rd + j] = apply_act(t + (b1 ? b1[j] : 0.f), act);
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float s = b2 ? b2[c] : 0.f;
-    const float* wr = w2 + (int64_t)c * rd;
-    for (int j = 0; j < rd; ++j) s += wr[j] * hid[j];
-    gate[(int64_t)b * C + c] = apply_act(s, gate_act);
+    float s[SE_IMG];
+    const float bv = b2 ? b2[c] : 0.f;
+#pragma unroll
+    for (int im = 0; im < SE_IMG; ++im) s[im] = bv;
+    for (int j = 0; j < rd; ++j) {
+      const float wv = w2[(int64_t)j * C + c];
+#pragma unroll
+      for (int im = 0; im < SE_IMG; ++im) s[im] += wv * hid[im * rd + j];
+    }
+#pragma unroll
+    for (int im = 0; im < SE_IMG; ++im)
+      if (b0 + im < B) gate[(int64_t)(b0 + im) * C + c] = apply_act(s[im], gate_act);
   }
 }
 
@@ -1247,9 +1274,15 @@ extern "C" int tfimm_hip_se_gate(const float* sums, float inv_count, const float
                                  const float* w2, const float* b2, float* gate, int B, int C, int rd, int act,
                                  int gate_act, void* stream) {
   if (!sums || !w1 || !w2 || !gate || B <= 0 || C <= 0 || rd <= 0) TFIMM_FAIL(TFIMM_EINVAL, "se_gate: bad arguments");
-  const size_t lds = (size_t)(C + rd) * sizeof(float);
-  if (lds > 64 * 1024) TFIMM_FAIL(TFIMM_EUNSUP, "se_gate: C + rd = %d too large", C + rd);
-  TFIMM_LAUNCH(se_gate_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, sums, inv_count, w1, b1, w2, b2, gate, C, rd, act, gate_act);
+  const size_t lds = (size_t)SE_IMG * (C + rd) * sizeof(float);
+  if (lds > 160 * 1024) TFIMM_FAIL(TFIMM_EUNSUP, "se_gate: C + rd = %d too large", C + rd);
+  static bool attr_done = false;
+  if (!attr_done) {
+    TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)se_gate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  TFIMM_LAUNCH(se_gate_kernel, dim3((B + SE_IMG - 1) / SE_IMG), dim3(1024), lds, (hipStream_t)stream, sums, inv_count, w1, b1, w2, b2,
+               gate, B, C, rd, act, gate_act);
   return 0;
 }
 

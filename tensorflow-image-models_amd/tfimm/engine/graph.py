@@ -521,7 +521,7 @@ class Builder:
         consts = {
             "w1": p.new_const(np.ascontiguousarray(w1[0, 0].T), w_reduce),
             "b1": p.new_const(self.wget(b_reduce), b_reduce),
-            "w2": p.new_const(np.ascontiguousarray(w2[0, 0].T), w_expand),
+            "w2": p.new_const(np.ascontiguousarray(w2[0, 0]), w_expand),     # [rd][C] as stored
             "b2": p.new_const(self.wget(b_expand), b_expand),
         }
         gate = p.new_tensor(1, c, dtype="f32", name="se_gate")

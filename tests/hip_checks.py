@@ -583,11 +583,9 @@ CASES["dwconv_k7_p3_c12_sums"] = lambda: _dw_case(2, 9, 9, 16, 7, 1, 3, "swish",
 CASES["dwconv_k3_p1_generic_c6"] = lambda: _dw_case(2, 8, 8, 6, 3, 1, 1, "relu", 95)
 
 
-@case("se_gate_and_scale")
-def _():
+def _se_case(B, R, Cc, rd, seed):
     import hip_ops as H
-    r = _rng(96)
-    B, R, Cc, rd = 3, 25, 144, 6
+    r = _rng(seed)
     x = _bf(r.standard_normal((B, R, Cc)))
     w1 = (r.standard_normal((rd, Cc)) / 12).astype(np.float32)
     b1 = r.standard_normal(rd).astype(np.float32)
@@ -597,12 +595,17 @@ def _():
     mean = torch.from_numpy(sums / R)
     hid = O.activation(mean @ torch.from_numpy(w1.T) + torch.from_numpy(b1), "swish")
     gate = torch.sigmoid(hid @ torch.from_numpy(w2.T) + torch.from_numpy(b2)).numpy()
-    g = H.se_gate(H.dev_f32(sums), 1.0 / R, H.dev_f32(w1), H.dev_f32(b1), H.dev_f32(w2), H.dev_f32(b2), "swish")
+    g = H.se_gate(H.dev_f32(sums), 1.0 / R, H.dev_f32(w1), H.dev_f32(b1), H.dev_f32(np.ascontiguousarray(w2.T)), H.dev_f32(b2), "swish")
     res = _bf(r.standard_normal((B, R, Cc)))
     y = H.scale_channels(H.dev_bf16(x), g, H.dev_bf16(res), relu_after=True)
     H.sync()
     ref_y = np.maximum(x * gate[:, None, :] + res, 0)
     return max(_err(_cpu(g), gate), _err(_cpu(y), ref_y)), TOL_BF16
+
+
+CASES["se_gate_and_scale"] = lambda: _se_case(3, 25, 144, 6, 96)           # 3 images: one partly filled group of 4
+CASES["se_gate_and_scale_b9_c1632"] = lambda: _se_case(9, 4, 1632, 68, 103)    # EfficientNet-B4's widest gate, 3 groups
+CASES["se_gate_and_scale_b4_c24_rd1"] = lambda: _se_case(4, 9, 24, 1, 104)
 
 
 def _patch_merge_case(B, Hh, Ww, Cc, seed):
