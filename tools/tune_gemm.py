@@ -30,7 +30,10 @@ def main():
         m.set_weights(synthetic_weights(m))
         plan = m.program().make_plan(int(b))
         n = plan.autotune(iters=5, verbose=verbose)
-        print(f"{spec}: tuned {n} new shapes, table size {len(tune.TABLE)}", flush=True)
+        cfg = m.cfg
+        x = torch.randn(int(b), *cfg.input_size, cfg.in_channels, device="cuda").to(torch.bfloat16)
+        ch = plan.autotune_in_context(x, top=4, iters=3, verbose=verbose) if n else 0
+        print(f"{spec}: tuned {n} new shapes ({ch} changed by the in-context pass), table size {len(tune.TABLE)}", flush=True)
         del plan, m
         torch.cuda.empty_cache()
     tune.save()
