@@ -2,6 +2,7 @@
 // Kernel: gemm_kernel.h; per-tile instantiations: gemm_inst.hip.
 #include "gemm_stream_kernel.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 using namespace tfimm_gemm;
@@ -109,7 +110,7 @@ int pick_dma_tile(const tfimm_gemm_desc& d) {
 // ceil(tiles / slots) rounds; score = efficiency x useful area x fill of those rounds.
 int pick_stream_tile(const tfimm_gemm_desc& d, const int* occ) {
   if (d.tile_hint > 20 && d.tile_hint <= 20 + TFIMM_GEMM_STREAM_NUM_TILES) return d.tile_hint - 21;
-  static const double eff[TFIMM_GEMM_STREAM_NUM_TILES] = {1.00, 0.90, 0.75, 0.70, 0.55, 0.90, 0.75, 0.0};
+  static const double eff[TFIMM_GEMM_STREAM_NUM_TILES] = {1.00, 0.90, 0.75, 0.70, 0.55, 0.90, 0.75, 0.0, 0.40};
   const int cus = num_cu();
   int best = 2;
   double best_score = -1.0;
@@ -162,6 +163,28 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
   if (d.mode < 0 || d.mode > 2) TFIMM_FAIL(TFIMM_EINVAL, "gemm: mode=%d", d.mode);
   if (d.remap_in < 0 || d.res_mod < 0) TFIMM_FAIL(TFIMM_EINVAL, "gemm: negative remap/res_mod");
   if (d.bias && ((uintptr_t)d.bias & 15)) TFIMM_FAIL(TFIMM_EINVAL, "gemm: bias must be 16-byte aligned");
+
+  // The LDS-DMA kernels address every tensor through a buffer descriptor with a 32-bit byte offset.  A plain
+  // dense GEMM whose activation, output or residual exceeds 2 GiB (EfficientNet-B4's first expand layer at batch 256:
+  // 9.2 M rows x 144 channels) is therefore run as row chunks that each fit, instead of leaving those families.
+  if (d.mode == TFIMM_A_DENSE && !d.a_scale && d.remap_in == 0 && d.res_mod == 0) {
+    const int64_t row_bytes = std::max<int64_t>(std::max<int64_t>((int64_t)d.lda * 2, (int64_t)d.ldc * (d.out_f32 ? 4 : 2)),
+                                                 d.residual ? (int64_t)d.ldr * 2 : 0);
+    const int64_t limit = 0x7fffff00LL;
+    if (row_bytes > 0 && (int64_t)d.M * row_bytes > limit && row_bytes * 512 <= limit) {
+      const int64_t chunk = (limit / row_bytes) / 256 * 256;
+      for (int64_t m0 = 0; m0 < d.M; m0 += chunk) {
+        tfimm_gemm_desc c = d;
+        c.M = (int32_t)std::min<int64_t>(chunk, d.M - m0);
+        c.a = (const char*)d.a + m0 * d.lda * 2;
+        c.out = (char*)d.out + m0 * d.ldc * (d.out_f32 ? 4 : 2);
+        if (d.residual) c.residual = (const char*)d.residual + m0 * d.ldr * 2;
+        const int rc = tfimm_hip_gemm(&c, stream);
+        if (rc != 0) return rc;
+      }
+      return 0;
+    }
+  }
 
   GemmArgs g;
   g.a = (const bf16_t*)d.a; g.wt = (const bf16_t*)d.wt; g.bias = d.bias;
@@ -221,11 +244,12 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
     const int64_t out_bytes = ((out_rows - 1) * d.ldc + d.N) * (d.out_f32 ? 4 : 2);
     const int64_t res_rows = d.res_mod > 0 ? (d.res_mod < d.M ? d.res_mod : d.M) : d.M;
     const int64_t res_bytes = d.residual ? ((res_rows - 1) * d.ldr + d.N) * 2 : 0;
-    const bool ok = (kmode == K_DENSE || kmode == K_CONV) && !hinted_other && !stream_disabled() && !dma_disabled() &&
+    const bool scale = kmode == K_DENSE_SCALE;
+    const bool ok = (kmode == K_DENSE || kmode == K_CONV || scale) && !hinted_other && !stream_disabled() && !dma_disabled() &&
                     d.ldw >= (int)(cdiv64(d.K, 64) * 64) && a_bytes <= 0x7fffff00LL && w_bytes <= 0x7fffff00LL &&
                     out_bytes <= 0x7fffff00LL && res_bytes <= 0x7fffff00LL;
     if (ok) {
-      const int fi = kmode == K_DENSE ? 0 : 1;
+      const int fi = kmode == K_CONV ? 1 : 0;
       // vector epilogue: whole 16-byte groups per lane on aligned rows
       const int vi = ((d.N % 8) == 0 && !d.out_f32 && g.out_vec16 && (!d.residual || g.res_vec16) &&
                       (d.res_mod == 0 || d.res_mod >= 128) && (d.remap_in == 0 || d.remap_in >= 128)) ? 1 : 0;
@@ -244,8 +268,12 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       }
       int occ_f[TFIMM_GEMM_STREAM_NUM_TILES];
       for (int i = 0; i < TFIMM_GEMM_STREAM_NUM_TILES; ++i) occ_f[i] = occ[i][fi];
-      const int ti = pick_stream_tile(d, occ_f);
+      int ti = pick_stream_tile(d, occ_f);
       const StreamTileCfg* t = stream_tile_table(ti);
+      if (scale && !t->fn_scale[vi]) {   // the deep-ring tile has no SE-gate flavour
+        ti = 0;
+        t = stream_tile_table(ti);
+      }
       GemmStreamArgs ga;
       ga.g = g;
       ga.g.tiles_m = (int)cdiv64(d.M, t->bm);
@@ -273,8 +301,34 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       grid = (grid + 7) / 8 * 8;
       const int64_t need = (ntiles + 7) / 8 * 8;
       if (grid > need) grid = need;
-      TFIMM_LAUNCH(t->fn[fi][vi], dim3((unsigned)grid), dim3(t->threads), (size_t)t->lds_bytes, (hipStream_t)stream, ga);
-      return 0;
+      ga.s_bytes = 0; ga.s_slots = ga.s_stride = ga.s_pieces = 0;
+      if (!scale) {
+        TFIMM_LAUNCH(t->fn[fi][vi], dim3((unsigned)grid), dim3(t->threads), (size_t)t->lds_bytes, (hipStream_t)stream, ga);
+        return 0;
+      }
+      // SE gate on A: the gate rows of the images a tile touches ride in LDS next to the operand ring (two buffers)
+      const int nw = t->threads / 64;
+      const int64_t nimg = cdiv64(d.M, d.rows_per_image);
+      ga.s_bytes = (unsigned)(nimg * d.K * 4);
+      ga.s_slots = (int)cdiv64(t->bm, d.rows_per_image) + 1;
+      ga.s_stride = (int)(cdiv64(d.K, 256) * 256);
+      ga.s_pieces = (int)cdiv64((int64_t)ga.s_slots * (ga.s_stride / 256), nw);
+      const size_t lds = (size_t)t->lds_bytes + (size_t)2 * ga.s_pieces * nw * 1024;
+      if (lds <= 160 * 1024 && nimg * d.K * 4 <= 0x7fffff00LL) {
+        static bool scale_attr[TFIMM_GEMM_STREAM_NUM_TILES][2] = {};
+        if (!scale_attr[ti][vi]) {
+          TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)t->fn_scale[vi], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          scale_attr[ti][vi] = true;
+        }
+        // resident workgroups per CU with the gate buffers counted in
+        int occ_s = (int)((160 * 1024) / lds);
+        occ_s = occ_s < 1 ? 1 : (occ_s > occ_f[ti] ? occ_f[ti] : occ_s);
+        grid = ((int64_t)num_cu() * occ_s + 7) / 8 * 8;
+        if (grid > need) grid = need;
+        TFIMM_LAUNCH(t->fn_scale[vi], dim3((unsigned)grid), dim3(t->threads), lds, (hipStream_t)stream, ga);
+        return 0;
+      }
+      // does not fit: the register-staged kernel below
     }
   }
 

@@ -42,6 +42,12 @@ struct GemmStreamArgs {
   int n_tiles;       // tiles_m * tiles_n
   int cin64;         // K_CONV: Cin % 64 == 0 (scalar tap stepping)
   unsigned cin_magic, kw_magic;   // K_CONV otherwise: floor(2^32 / d) + 1 for d = Cin, KW (0: K >= 65536, divide)
+  // SCALE flavour (SE gate on the A operand, a_scale[image][k]): gate rows of the images a tile touches are
+  // brought into LDS by the same DMA stream as the operands
+  unsigned s_bytes;   // extent of the gate table
+  int s_slots;        // image slots per tile: ceil(BM / rows_per_image) + 1
+  int s_stride;       // floats per slot (K rounded up to whole 1-KiB DMA pieces)
+  int s_pieces;       // DMA pieces per wave and tile (slots * stride / 256 / waves, rounded up)
   long long* dbg_ptr; // TFIMM_GEMM_DBG_PTR: s_memtime stamps of workgroup 0 (dbg & 64)
   int dbg;           // TFIMM_GEMM_DBG: bit 64 = record the stamps (tools/gemm_stamps.py)
 };
@@ -60,7 +66,7 @@ struct StreamGeom {
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit in LDS");
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int KMODE, bool VEC>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KMODE, bool VEC, bool SCALE = false>
 __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(const GemmStreamArgs pa) {
   using G = StreamGeom<BM, BN, WAVES_M, WAVES_N>;
   const GemmArgs& p = pa.g;
@@ -72,6 +78,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   static_assert(A_INSTR >= 1 && B_INSTR >= 1 && TM >= 1 && TN >= 1, "tile/wave mismatch");
   static_assert(KMODE == K_DENSE || KMODE == K_CONV, "LDS-DMA flavours: dense rows or Cin % 8 == 0 gather");
   static_assert(WTN == 32 || WTN == 64, "epilogue swizzle is written for 32/64-wide wave tiles");
+  static_assert(!SCALE || KMODE == K_DENSE, "the SE-gate prologue exists for dense rows");
   constexpr int A_BYTES = G::A_BYTES, STAGE = G::STAGE;
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
@@ -100,6 +107,10 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(p.wt, pa.w_bytes);
   const __amdgpu_buffer_rsrc_t rsrc_o = make_rsrc(p.out, pa.out_bytes);
   const __amdgpu_buffer_rsrc_t rsrc_r = make_rsrc(p.residual, pa.res_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_s = make_rsrc(p.a_scale, SCALE ? pa.s_bytes : 0u);
+  // gate region: two buffers (tile being multiplied / tile being issued) of s_pieces * NW pieces of 256 floats
+  float* const sS = reinterpret_cast<float*>(smem + G::LDS_BYTES);
+  const int s_buf_floats = SCALE ? pa.s_pieces * NW * 256 : 0;
 
   const int nk = (p.K + BK - 1) / BK;
   const int lrow = lane >> 3;   // row within an 8-row DMA piece
@@ -206,6 +217,24 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
       }
     }
   };
+  // gate rows of the images tile `tile` touches -> gate buffer `buf`.  Piece pi covers floats [256 (pi % ppr),
+  // +256) of slot pi / ppr (ppr = pieces per slot); anything outside the table (k >= K, image >= B, pi beyond the
+  // last slot) has an out-of-range offset and lands as zeros
+  auto issue_scales = [&](int tile, bool valid, int buf) __attribute__((always_inline)) {
+    const int mt = tile / p.tiles_n;
+    const int b0 = (mt * BM) / p.rows_per_image;
+    const int ppr = pa.s_stride >> 8;
+    for (int j = 0; j < pa.s_pieces; ++j) {
+      const int pi = wave + j * NW;
+      const int slot = pi / ppr, q = pi - slot * ppr;
+      const int k = q * 256 + lane * 4;
+      const int img = b0 + slot;
+      const bool ok = valid && slot < pa.s_slots && k < p.K && (int64_t)img * p.rows_per_image < p.M;
+      const unsigned off = ok ? (unsigned)(((size_t)img * p.K + k) * 4) : kOobOffset;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_s, (lds_ptr_t)(sS + buf * s_buf_floats + pi * 256), 16, (int)off, 0, 0, 0);
+    }
+  };
+  int s_iss = 0;   // gate buffer the next issued tile writes
   auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < N_PIECES; ++q) issue_piece(q, kt, stage);
@@ -231,8 +260,10 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   // ---- prime the pipeline
   int iss_tile = t_first, iss_kt = 1;
   setup_issue(iss_tile, true);
+  if (SCALE) { issue_scales(iss_tile, true, s_iss); s_iss ^= 1; }
   issue(0, 0);
   int cur = 0;
+  int s_cmp = 0;   // gate buffer of the tile being multiplied
   bool stores_pending = false;   // the previous step ended an interior tile: its stores may still be in flight
   int stamp_i = 0;
   auto stamp = [&]() __attribute__((always_inline)) {
@@ -292,6 +323,20 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
       rres[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, (int)off, 0, 0));
     };
 
+    // SCALE: LDS offset (floats) of the gate row of each fragment row's image, relative to the tile's first image
+    const float* s_cur = sS + s_cmp * s_buf_floats;
+    int s_off[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) s_off[i] = 0;
+    if (SCALE) {
+      const int b0 = m0 / p.rows_per_image;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WTM + i * 32 + frow;
+        s_off[i] = ((m < p.M ? m : p.M - 1) / p.rows_per_image - b0) * pa.s_stride;
+      }
+    }
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -301,7 +346,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // one step of the flattened (tile, k-tile) pipeline; `last` = final k-tile of this tile
-    auto kstep = [&](bool last) __attribute__((always_inline)) {
+    auto kstep = [&](bool last, int kt_cur) __attribute__((always_inline)) {
       // This wave's DMA pieces of the current step must have landed.  VMEM operations retire in
       // issue order, and the only ones younger than that DMA are the previous tile's epilogue
       // (>= TM*ITS store instructions for an interior tile): leave exactly those in flight.
@@ -324,6 +369,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
         iss_tile += t_step;
         iss_kt = 0;
         setup_issue(iss_tile, iss_tile < t_hi);
+        if (SCALE) { issue_scales(iss_tile, iss_tile < t_hi, s_iss); s_iss ^= 1; }
       }
       issue(iss_kt, cur ^ 1);
       ++iss_kt;
@@ -339,6 +385,20 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           fb[j] = __builtin_bit_cast(bf16x8, sB[lds_slot(wn * WTN + j * 32 + frow, ks * 2 + fhi)]);
+        if (SCALE) {
+          // a[m][k] * gate[image(m)][k] on the fragment (8 consecutive k of one row per lane), rounded to bf16 once
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const float4* gp = reinterpret_cast<const float4*>(s_cur + s_off[i] + kt_cur * BK + ks * 16 + fhi * 8);
+            const float4 g0 = gp[0], g1 = gp[1];
+            const uint4 u = __builtin_bit_cast(uint4, fa[i]);
+            tfimm_f32x2 v[4];
+            unpack8p(u, v);
+            v[0] *= tfimm_f32x2{g0.x, g0.y}; v[1] *= tfimm_f32x2{g0.z, g0.w};
+            v[2] *= tfimm_f32x2{g1.x, g1.y}; v[3] *= tfimm_f32x2{g1.z, g1.w};
+            fa[i] = __builtin_bit_cast(bf16x8, pack8p(v));
+          }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -349,8 +409,9 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
     };
 
     stamp();
-    for (int kt = 0; kt + 1 < nk; ++kt) kstep(false);
-    kstep(true);
+    for (int kt = 0; kt + 1 < nk; ++kt) kstep(false, kt);
+    kstep(true, nk - 1);
+    s_cmp ^= 1;
     stamp();
 
     // ---- epilogue (per wave).  Aliased staging lives in the stage consumed last (index cur^1 now):
@@ -364,6 +425,9 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
     } else {
       sEw = reinterpret_cast<float*>(smem + 2 * STAGE + wave * G::EPI_WAVE);
     }
+    // a wave whose 32/64 columns all lie beyond N has nothing to store (ragged N: the last column tile); such a
+    // tile is never `interior`, so the counted wait of the next step does not expect its stores
+    if (!(VEC && n0 + wn * WTN >= p.N))
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       // The staging stores below are inline asm, and hipcc pads no hazards inside or in front of an
@@ -460,6 +524,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
 struct StreamTileCfg {
   int bm, bn, threads, lds_bytes;
   gemm_stream_fn fn[2][2];  // [K_DENSE, K_CONV][catch-all, VEC]
+  gemm_stream_fn fn_scale[2];  // K_DENSE + SE gate on A: [catch-all, VEC] (null: not built for this tile)
 };
 
 }  // namespace tfimm_gemm
@@ -472,6 +537,8 @@ struct StreamTileCfg {
   X(3, 256, 64, 4, 2)              \
   X(4, 128, 64, 2, 2)              \
   X(5, 128, 256, 2, 4)             \
-  X(6, 256, 64, 4, 1)
-// id 7 = the 256x256 deep-ring schedule (gemm_pipe_kernel.h), instantiated on its own
-#define TFIMM_GEMM_STREAM_NUM_TILES 8
+  X(6, 256, 64, 4, 1)             \
+  X(8, 256, 32, 4, 1)
+// id 7 = the 256x256 deep-ring schedule (gemm_pipe_kernel.h), instantiated on its own; id 8 = narrow outputs
+// (N <= 32 per tile: the 24..48-channel layers of EfficientNet / MobileNet)
+#define TFIMM_GEMM_STREAM_NUM_TILES 9

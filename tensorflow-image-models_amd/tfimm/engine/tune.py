@@ -9,13 +9,13 @@
     buffers before the first forward.
 Hints: 0 = library cost model, 11..16 = one-tile-per-workgroup LDS-DMA tiles, 21..26 =
 persistent LDS-DMA tiles (ids: 256x256, 256x128, 128x128, 256x64, 128x64, 128x256; 27 = 256x64 with
-64x64 wave tiles; 28 = 256x256 with the four-stage ring of gemm_pipe_kernel.h).
+64x64 wave tiles; 28 = 256x256 with the four-stage ring of gemm_pipe_kernel.h; 29 = 256x32 for narrow outputs).
 """
 import json
 import os
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tune.json")
-CANDIDATES = (0, 21, 22, 23, 24, 25, 26, 27, 28, 11, 12, 13, 14, 15, 16)
+CANDIDATES = (0, 21, 22, 23, 24, 25, 26, 27, 28, 29, 11, 12, 13, 14, 15, 16)
 TABLE = {}
 _autotune = os.environ.get("TFIMM_AUTOTUNE", "0") == "1"
 
@@ -31,10 +31,11 @@ def autotune_enabled() -> bool:
 
 def key_of(d) -> str:
     """Everything that changes the kernel's work: GEMM extents, operand strides, conv geometry and
-    the epilogue flavour (residual / fp32 output change the epilogue's memory traffic)."""
+    the epilogue flavour (residual / fp32 output change the epilogue's memory traffic) and the SE-gate
+    prologue."""
     return ":".join(str(int(v)) for v in (
         d.mode, d.M, d.N, d.K, d.lda, d.ldc, d.H, d.W, d.Cin, d.KH, d.KW, d.stride,
-        1 if d.residual else 0, d.out_f32, d.act))
+        1 if d.residual else 0, d.out_f32, d.act, 1 if d.a_scale else 0))
 
 
 def lookup(d) -> int:

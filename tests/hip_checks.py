@@ -94,16 +94,16 @@ def _gemm_case(M, K, N, *, act="", bias=True, residual=False, act_after_res=Fals
     return _err(got, ref), (TOL_F32 if out_f32 else TOL_BF16)
 
 
-# tile hints: 0 auto, 1..6 register-staged tiles, 11..16 LDS-DMA tiles, 21..27 persistent LDS-DMA tiles,
+# tile hints: 0 auto, 1..6 register-staged tiles, 11..16 LDS-DMA tiles, 21..27 and 29 persistent LDS-DMA tiles,
 # 28 the 256x256 deep-ring schedule
-for _t in list(range(0, 7)) + list(range(11, 17)) + list(range(21, 29)):
+for _t in list(range(0, 7)) + list(range(11, 17)) + list(range(21, 30)):
     CASES[f"gemm_tile{_t:02d}_256x192x320"] = (lambda t=_t: _gemm_case(256, 192, 320, tile=t, seed=1))
     CASES[f"gemm_tile{_t:02d}_ragged_333x200x150_gelu_res"] = (
         lambda t=_t: _gemm_case(333, 200, 150, act="gelu", residual=True, tile=t, seed=2))
     CASES[f"gemm_tile{_t:02d}_600x320x520_relu_after_res_f32"] = (
         lambda t=_t: _gemm_case(600, 320, 520, act="relu", residual=True, act_after_res=True, out_f32=True, tile=t,
                                 seed=3))
-for _t in range(21, 29):
+for _t in range(21, 30):
     # more tiles than resident workgroups: every persistent workgroup walks several tiles (ragged M, N, K)
     CASES[f"gemm_stream_multiround_tile{_t:02d}"] = (
         lambda t=_t: _gemm_case(40000, 200, 520, act="gelu", residual=True, tile=t, seed=50 + t))
@@ -124,20 +124,36 @@ CASES["gemm_sigmoid_relu6"] = lambda: max(_gemm_case(64, 64, 64, act="sigmoid", 
                                           _gemm_case(64, 64, 64, act="relu6", seed=14))
 
 
-@case("gemm_se_scale_prologue")
-def _():
+def _se_scale_case(B, R, K, N, seed, tile=0, residual=False, bias=False):
+    """SE gate folded into the projection conv: (a * gate[image]) @ W (efficientnet_blocks.py:241-248,447-449)."""
     import hip_ops as H
-    r = _rng(20)
-    B, R, K, N = 3, 50, 48, 24
+    r = _rng(seed)
     a = _bf(r.standard_normal((B * R, K)))
     w = _bf(r.standard_normal((K, N)) / math.sqrt(K))
     g = r.uniform(0.1, 1.0, (B, K)).astype(np.float32)
-    wt, _ = pack.pack_dense(w, None)
+    bvec = r.standard_normal(N).astype(np.float32) if bias else None
+    res = _bf(r.standard_normal((B * R, N))) if residual else None
+    wt, bp = pack.pack_dense(w, bvec)
     scaled = _bf(a.reshape(B, R, K) * g[:, None, :]).reshape(B * R, K)   # kernel re-rounds A*gate to bf16
     ref = scaled.astype(np.float64) @ w.astype(np.float64)
-    got = H.gemm(H.dev_bf16(a), H.dev_bits(wt), N, K, a_scale=H.dev_f32(g), rows_per_image=R)
+    if bias:
+        ref = ref + bvec
+    if residual:
+        ref = ref + res
+    got = H.gemm(H.dev_bf16(a), H.dev_bits(wt), N, K, a_scale=H.dev_f32(g), rows_per_image=R, tile_hint=tile,
+                 bias=None if bp is None else H.dev_f32(bp), residual=None if res is None else H.dev_bf16(res))
     H.sync()
     return _err(_cpu(got), ref), TOL_BF16
+
+
+CASES["gemm_se_scale_prologue"] = lambda: _se_scale_case(3, 50, 48, 24, 20)
+for _t in (1, 21, 22, 23, 24, 25, 26, 27, 29):
+    # rows_per_image 144 < tile height: a tile spans 2-3 images; K = 200 is not a whole k-tile / gate piece
+    CASES[f"gemm_se_scale_tile{_t:02d}_r144_k200"] = (
+        lambda t=_t: _se_scale_case(11, 144, 200, 72, 110 + t, tile=t, residual=True, bias=True))
+CASES["gemm_se_scale_t24_r2304_k960"] = lambda: _se_scale_case(5, 2304, 960, 160, 130, tile=24, residual=True)   # several gate pieces per slot
+CASES["gemm_se_scale_t23_r9025_k144_multiround"] = lambda: _se_scale_case(9, 9025, 144, 32, 131, tile=23, bias=True)
+CASES["gemm_se_scale_t21_r36_k2688"] = lambda: _se_scale_case(40, 36, 2688, 448, 132, tile=21)   # 9 images per tile: gate buffers fit only for a narrow tile -> falls back
 
 
 @case("gemm_row_select_lda")
@@ -220,7 +236,7 @@ CASES["conv3x3_s2_same_even"] = lambda: _conv_case(2, 20, 20, 16, 24, 3, 2, "sam
 CASES["conv3x3_scalar_cin6"] = lambda: _conv_case(2, 8, 8, 6, 10, 3, 1, 1, act="relu", seed=39)
 CASES["conv3x3_scalar_cin2_s2"] = lambda: _conv_case(3, 9, 9, 2, 4, 3, 2, 1, seed=40)
 CASES["conv1ch_8x8_patch"] = lambda: _conv_case(2, 32, 32, 1, 4, 8, 8, 0, bn=False, seed=41)
-for _t in (1, 2, 3, 4, 5, 6, 11, 12, 13, 14, 15, 16, 21, 22, 23, 24, 25, 26, 27, 28):
+for _t in (1, 2, 3, 4, 5, 6, 11, 12, 13, 14, 15, 16, 21, 22, 23, 24, 25, 26, 27, 28, 29):
     CASES[f"conv3x3_tile{_t:02d}"] = (lambda t=_t: _conv_case(2, 16, 16, 64, 96, 3, 1, 1, act="relu", seed=42, tile=t))
     CASES[f"conv3x3_s2_res_tile{_t:02d}"] = (
         lambda t=_t: _conv_case(3, 15, 13, 40, 72, 3, 2, 1, act="relu", residual=True, seed=43, tile=t))
@@ -244,6 +260,8 @@ CASES["gemm_t21_resmod_remap_19600x192x768"] = lambda: _gemm_case(19600, 192, 76
                                                                  remap=(196, 197, 1), tile=21, seed=96)
 CASES["conv3x3_t21_cin128_multiround"] = lambda: _conv_case(24, 28, 28, 128, 256, 3, 1, 1, act="relu", residual=True, seed=94, tile=21)
 CASES["conv3x3_t21_cin40_s2"] = lambda: _conv_case(16, 31, 29, 40, 264, 3, 2, 1, act="relu", seed=95, tile=21)
+CASES["gemm_t29_n24_res_70000x48"] = lambda: _gemm_case(70000, 48, 24, residual=True, tile=29, seed=105)   # narrow-output tile
+CASES["gemm_t24_n144_swish_ragged_tiles"] = lambda: _gemm_case(30000, 24, 144, act="swish", tile=24, seed=106)  # last column tile: one wave fully out of range
 for _t in (21, 28):
     CASES[f"gemm_t{_t}_resmod_remap_19600x200x768"] = (
         lambda t=_t: _gemm_case(19600, 200, 768, residual=True, res_mod=196, remap=(196, 197, 1), tile=t, seed=97))
