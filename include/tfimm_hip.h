@@ -106,7 +106,10 @@ typedef struct tfimm_gemm_desc {
   int32_t mode;
   int32_t B, H, W, Cin, KH, KW, stride, pad_t, pad_l, OH, OW;
   int32_t rows_per_image;
-  int32_t tile_hint;      /* 0 = auto; otherwise index into the kernel table (benchmarks) */
+  int32_t tile_hint;      /* 0 = the library's cost model; otherwise a kernel-table index measured by the caller
+                             (tfimm/engine/tune.py): 1..6 register-staged tiles, 11..16 one-tile LDS-DMA kernels,
+                             21..29 persistent LDS-DMA kernels (28 = 256x256 deep ring, 29 = 256x32).  A hint the
+                             problem cannot use (alignment, flavour not built) falls back to the cost model. */
   int32_t stride_w;       /* TFIMM_A_CONV only: horizontal stride if it differs from `stride` (0 = same).
                              Lets a stride-2 RGB stem / patch embedding run on the pixel-PAIR view of a
                              zero-padded 4-channel image ([B][Hp][Wp/2][8], see tfimm_hip_cast_input_pad):
