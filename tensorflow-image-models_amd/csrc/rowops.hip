@@ -542,195 +542,15 @@ __global__ void __launch_bounds__(256) dwconv_strip_kernel(const bf16_t* __restr
 }
 
 // ---------------------------------------------------------------------------------------
-// Marching kernel (C % 4 == 0): a thread owns 4 channels x PX adjacent output columns and walks DOWN
-// a segment of output rows with a sliding window of K (+ S prefetched) input rows in registers (packed bf16),
-// so every input row is fetched ONCE per thread instead of once per filter row -- the strip kernel
-// above re-read each input row K times and the re-reads missed L2 (rocprofv3: FETCH_SIZE 3x the
-// input, TCC hit rate 37 %, SQ_WAIT_ANY 75 % of wave cycles on EfficientNet-B4's 95x95x192 layer).
-// The S rows of the NEXT output row are requested before the current row's FMAs (that is what the
-// S extra rows are for); the window slides by register moves.  Filter taps come from LDS ([tap][channel], one tile of 256 channels per
-// workgroup); the SE squeeze is accumulated per thread over its whole segment.
-// ---------------------------------------------------------------------------------------
-constexpr int dw_gcd(int a, int b) { return b == 0 ? a : dw_gcd(b, a % b); }
-
-template <int K, int S, int PX, int CV>
-__global__ void __launch_bounds__(256) dwconv_march_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, bf16_t* __restrict__ y,
-                                                           float* sum_out, int H, int W, int C, int pad_t, int pad_l,
-                                                           int OH, int OW, int act, int rows_per_seg, int nseg) {
-  static_assert(CV == 2 || CV == 4, "2 or 4 channels per thread");
-  typedef typename std::conditional<CV == 4, uint2, uint32_t>::type raw_t;
-  constexpr int COLS = (PX - 1) * S + K;
-  extern __shared__ float dw_lds[];
-  float* wl = dw_lds;                            // [K*K][256]
-  float* lsum = dw_lds + K * K * 256;            // [256]
-
-  const int tid = threadIdx.x;
-  const int b = blockIdx.y;
-  const int cgs = C / CV;
-  const int CGB = min(cgs, 256 / CV);            // channel groups per workgroup (a tile of <= 256 channels)
-  const int SPB = 256 / CGB;                     // column strips x row segments per workgroup
-  const int ctiles = (cgs + CGB - 1) / CGB;
-  const int ct = blockIdx.x % ctiles;
-  const int sblk = blockIdx.x / ctiles;
-  const int cgl = tid % CGB, sl = tid / CGB;
-  const int cg = ct * CGB + cgl;
-  const int c0 = cg * CV;
-  const int sx = (OW + PX - 1) / PX;
-  const int item = sblk * SPB + sl;              // (segment, strip), strip fastest
-  const int strip = item % sx, seg = item / sx;
-  const bool live = sl < SPB && cg < cgs && seg < nseg;
-  const ActParams actp = make_act(act);
-
-  for (int i = tid; i < K * K * 256; i += 256) {
-    const int tap = i >> 8, c = i & 255;
-    const int ch = ct * CGB * CV + c;
-    wl[i] = (c < CGB * CV && ch < C) ? w[(size_t)tap * C + ch] : 0.f;
-  }
-  if (sum_out) lsum[tid] = 0.f;
-  __syncthreads();
-
-  float tot[CV];
-#pragma unroll
-  for (int e = 0; e < CV; ++e) tot[e] = 0.f;
-  if (live) {
-    const int ox0 = strip * PX;
-    const int oy_begin = seg * rows_per_seg;
-    const int oy_end = min(OH, oy_begin + rows_per_seg);
-    const int iy_start = oy_begin * S - pad_t;
-    const int ixb = ox0 * S - pad_l;
-    // all arithmetic on channel PAIRS (tfimm_f32x2 -> v_pk_fma_f32 / v_pk_mul_f32: half the VALU instructions)
-    constexpr int CP = CV / 2;
-    tfimm_f32x2 bias2[CP];
-#pragma unroll
-    for (int i = 0; i < CP; ++i) bias2[i] = bias ? tfimm_f32x2{bias[c0 + 2 * i], bias[c0 + 2 * i + 1]} : tfimm_f32x2{0.f, 0.f};
-    const bf16_t* ximg = x + (size_t)b * H * W * C + c0;
-    int xoff[COLS];          // clamped column offsets (elements)
-    float cmask[COLS];
-#pragma unroll
-    for (int col = 0; col < COLS; ++col) {
-      const int ix = ixb + col;
-      cmask[col] = (unsigned)ix < (unsigned)W ? 1.f : 0.f;
-      xoff[col] = min(max(ix, 0), W - 1) * C;
-    }
-    tfimm_f32x2 win[K][COLS][CP];  // input rows of the current output row (fp32 pairs, zero outside the image)
-    raw_t nxt[S][COLS];      // the S rows the next output row adds, still packed (requested one row ahead)
-    float nmask[S];
-    auto load_row = [&](int j, raw_t* dst) __attribute__((always_inline)) -> float {   // input row iy_start + j
-      const int iy = iy_start + j;
-      const bool rok = (unsigned)iy < (unsigned)H;
-      const bf16_t* xrow = ximg + (size_t)(rok ? iy : 0) * W * C;
-#pragma unroll
-      for (int col = 0; col < COLS; ++col) dst[col] = *reinterpret_cast<const raw_t*>(xrow + xoff[col]);
-      return rok ? 1.f : 0.f;
-    };
-    auto unpack_row = [&](const raw_t* src, float rmask, tfimm_f32x2 (*dst)[CP]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int col = 0; col < COLS; ++col) {
-        const uint32_t* u = reinterpret_cast<const uint32_t*>(&src[col]);
-        const float m = rmask * cmask[col];
-#pragma unroll
-        for (int i = 0; i < CP; ++i)
-          dst[col][i] = m * tfimm_f32x2{__uint_as_float(u[i] << 16), __uint_as_float(u[i] & 0xffff0000u)};
-      }
-    };
-    {
-      raw_t tmp[COLS];
-#pragma unroll
-      for (int j = 0; j < K; ++j) {
-        const float rm = load_row(j, tmp);
-        unpack_row(tmp, rm, win[j]);
-      }
-    }
-
-#pragma unroll 1
-    for (int t = 0; oy_begin + t < oy_end; ++t) {
-      const int oy = oy_begin + t;
-      asm volatile("" ::: "memory");   // filter taps stay in LDS: no hoisting of the K*K reads out of the loop
-      // request the S new rows of output row t + 1 before this row's FMAs
-#pragma unroll
-      for (int i = 0; i < S; ++i) nmask[i] = load_row((t + 1) * S + K - S + i, nxt[i]);
-      tfimm_f32x2 acc[PX][CP];
-#pragma unroll
-      for (int px = 0; px < PX; ++px)
-#pragma unroll
-        for (int i = 0; i < CP; ++i) acc[px][i] = bias2[i];
-#pragma unroll
-      for (int ky = 0; ky < K; ++ky) {
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-          tfimm_f32x2 wv[CP];
-          if (CV == 4) {
-            const float4 w4 = *reinterpret_cast<const float4*>(&wl[(ky * K + kx) * 256 + cgl * 4]);
-            wv[0] = tfimm_f32x2{w4.x, w4.y}; wv[CP - 1] = tfimm_f32x2{w4.z, w4.w};
-          } else {
-            const float2 w2 = *reinterpret_cast<const float2*>(&wl[(ky * K + kx) * 256 + cgl * 2]);
-            wv[0] = tfimm_f32x2{w2.x, w2.y};
-          }
-#pragma unroll
-          for (int px = 0; px < PX; ++px)
-#pragma unroll
-            for (int i = 0; i < CP; ++i) acc[px][i] = __builtin_elementwise_fma(win[ky][px * S + kx][i], wv[i], acc[px][i]);
-        }
-      }
-      bf16_t* yrow = y + ((size_t)((size_t)b * OH + oy) * OW) * C + c0;
-#pragma unroll
-      for (int px = 0; px < PX; ++px) {
-#pragma unroll
-        for (int i = 0; i < CP; ++i) {
-          acc[px][i].x = act1(acc[px][i].x, actp);
-          acc[px][i].y = act1(acc[px][i].y, actp);
-        }
-        uint32_t pk[CP];
-#pragma unroll
-        for (int i = 0; i < CP; ++i) pk[i] = pack_bf2(acc[px][i].x, acc[px][i].y);
-        const bool ok = ox0 + px < OW;
-        if (ok) {
-          raw_t u;
-          uint32_t* uw = reinterpret_cast<uint32_t*>(&u);
-#pragma unroll
-          for (int i = 0; i < CV / 2; ++i) uw[i] = pk[i];
-          *reinterpret_cast<raw_t*>(yrow + (size_t)(ox0 + px) * C) = u;
-        }
-        const float m = ok ? 1.f : 0.f;      // the squeeze sees the stored (bf16-rounded) activations
-#pragma unroll
-        for (int i = 0; i < CV / 2; ++i) {
-          tot[2 * i] += m * bf2f(pk[i] & 0xffffu);
-          tot[2 * i + 1] += m * bf2f(pk[i] >> 16);
-        }
-      }
-      // slide the window down by S rows (register moves), convert the prefetched rows into it
-#pragma unroll
-      for (int j = 0; j + S < K; ++j)
-#pragma unroll
-        for (int col = 0; col < COLS; ++col)
-#pragma unroll
-          for (int i = 0; i < CP; ++i) win[j][col][i] = win[j + S][col][i];
-#pragma unroll
-      for (int i = 0; i < S; ++i) unpack_row(nxt[i], nmask[i], win[K - S + i]);
-    }
-  }
-  if (sum_out) {
-    if (live) {
-#pragma unroll
-      for (int e = 0; e < CV; ++e) atomicAdd(&lsum[cgl * CV + e], tot[e]);
-    }
-    __syncthreads();
-    const int ch = ct * CGB * CV + tid;
-    if (tid < CGB * CV && ch < C) atomicAdd(sum_out + (size_t)b * C + ch, lsum[tid]);
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// Stride-1 depthwise (k = 3 / 5 / 7; EfficientNet, ConvNeXt): 25 / 49 MACs per output make k = 5 / 7 VALU-bound
-// (12 / 24 flop per HBM byte), so the kernel is
+// Row-stationary depthwise kernel (k = 3 / 5 / 7 at stride 1, k = 3 / 5 at stride 2; EfficientNet, ConvNeXt).
+// 25 / 49 MACs per output make k = 5 / 7 VALU-bound (12 / 24 flop per HBM byte), so the kernel is
 // organised around packed FMAs with no register traffic besides them.  A thread owns ONE channel pair and PX = 4
-// adjacent output columns and marches down a row segment.  Every INPUT row is loaded once (PX + 6 pixel pairs,
-// requested one row ahead) and scattered into the 7 output rows it contributes to: seven accumulator rows
-// (7 x PX fp32 pairs) stay in registers, the row whose last contribution just arrived is stored and reset.  The
-// loop is unrolled over the 7 phases of that rotation, so accumulator slots are compile-time indices -- the
-// sliding fp32 window of the marching kernel above needs K x (PX + K - 1) pairs and register moves per row,
-// which is what limits it to k <= 5.  Filter taps: LDS [49][channel pair], one conflict-free 8-byte read per
+// adjacent output columns and marches down a row segment.  Every INPUT row is loaded once ((PX - 1) S + K pixel pairs,
+// requested one row ahead) and scattered into the ceil(K / S) output rows it contributes to: that many accumulator
+// rows (x PX fp32 pairs) stay in registers, the row whose last contribution just arrived is stored and reset.  The
+// loop is unrolled over the S * ceil(K / S) phases of that rotation, so accumulator slots are compile-time indices -- the
+// sliding fp32 window this kernel replaced needed K x (PX + K - 1) pairs and register moves per row, which limited
+// it to k <= 5.  Filter taps: LDS [K*K][channel pair], one conflict-free 8-byte read per
 // (tap, thread) feeding PX packed FMAs.
 // ---------------------------------------------------------------------------------------
 // channel pairs per workgroup (CPB) and with it column strips per workgroup (256 / CPB): the split of the 256
@@ -747,12 +567,14 @@ static int dw_rows_pairs_per_block(int cps, int sx) {
   return best;
 }
 
-template <int K, int PX>
+template <int K, int S, int PX>
 __global__ void __launch_bounds__(256) dwconv_rows_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, bf16_t* __restrict__ y,
                                                       float* sum_out, int H, int W, int C, int pad_t, int pad_l, int OH, int OW, int act,
                                                       int rows_per_seg, int nseg, int CPB) {
-  constexpr int COLS = PX + K - 1;
+  constexpr int COLS = (PX - 1) * S + K;
+  constexpr int NSLOT = (K + S - 1) / S;          // output rows with contributions pending
+  constexpr int PERIOD = S * NSLOT;              // input rows per full rotation of the slots
   extern __shared__ tfimm_f32x2 dw7_lds[];       // [K*K][CPB] filter taps of this workgroup's channel pairs, then [2 CPB] squeeze sums
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
@@ -785,14 +607,14 @@ __global__ void __launch_bounds__(256) dwconv_rows_kernel(const bf16_t* __restri
   const int c0 = cp * 2;
   const int ox0 = strip * PX;
   const int oy0 = seg * rows_per_seg, oy1 = min(OH, oy0 + rows_per_seg);
-  const int r_begin = oy0 - pad_t, r_end = oy1 + (K - 1) - pad_t;        // input rows [r_begin, r_end) touch this segment
+  const int r_begin = oy0 * S - pad_t, r_end = (oy1 - 1) * S + K - pad_t;   // input rows [r_begin, r_end) touch this segment
   const tfimm_f32x2 bias2 = bias ? tfimm_f32x2{bias[c0], bias[c0 + 1]} : tfimm_f32x2{0.f, 0.f};
   const bf16_t* ximg = x + (size_t)b * H * W * C + c0;
   int xoff[COLS];
   float cmask[COLS];
 #pragma unroll
   for (int col = 0; col < COLS; ++col) {
-    const int ix = ox0 - pad_l + col;
+    const int ix = ox0 * S - pad_l + col;
     cmask[col] = (unsigned)ix < (unsigned)W ? 1.f : 0.f;
     xoff[col] = min(max(ix, 0), W - 1) * C;
   }
@@ -801,18 +623,18 @@ __global__ void __launch_bounds__(256) dwconv_rows_kernel(const bf16_t* __restri
 #pragma unroll
     for (int col = 0; col < COLS; ++col) dst[col] = *reinterpret_cast<const uint32_t*>(xrow + xoff[col]);
   };
-  tfimm_f32x2 acc[K][PX];
+  tfimm_f32x2 acc[NSLOT][PX];
 #pragma unroll
-  for (int j = 0; j < K; ++j)
+  for (int j = 0; j < NSLOT; ++j)
 #pragma unroll
     for (int px = 0; px < PX; ++px) acc[j][px] = bias2;
   uint32_t raw[COLS];
   load_row(r_begin, raw);
   const tfimm_f32x2* wl = dw7_lds + cpl;
 
-  for (int rb = r_begin; rb < r_end; rb += K) {
+  for (int rb = r_begin; rb < r_end; rb += PERIOD) {
 #pragma unroll
-    for (int ph = 0; ph < K; ++ph) {
+    for (int ph = 0; ph < PERIOD; ++ph) {
       const int r = rb + ph;
       if (r < r_end) {                               // wave-uniform
         tfimm_f32x2 in[COLS];
@@ -822,38 +644,44 @@ __global__ void __launch_bounds__(256) dwconv_rows_kernel(const bf16_t* __restri
           in[col] = (rmask * cmask[col]) * tfimm_f32x2{__uint_as_float(raw[col] << 16), __uint_as_float(raw[col] & 0xffff0000u)};
         if (r + 1 < r_end) load_row(r + 1, raw);     // next input row in flight under this row's FMAs
         if ((unsigned)r < (unsigned)H) {
-          // input row r feeds output row oy = r + pad_t - ky, kept in slot (ph + K - 1 - ky) mod K
+          // input row r = r_begin + ph (mod PERIOD) feeds output row oy = (r + pad_t - ky) / S for the ky of its
+          // parity class (r_begin + pad_t is a multiple of S); oy lives in slot ((ph - ky) / S) mod NSLOT
 #pragma unroll
           for (int ky = 0; ky < K; ++ky) {
-            const int oy = r + pad_t - ky;
-            if (oy >= oy0 && oy < oy1) {             // wave-uniform: rows outside the segment belong to a neighbour
-              const int slot = (ph + (K - 1) - ky) % K;
+            if ((ky % S) != (ph % S)) continue;      // compile time
+            const int oy = (r + pad_t - ky) / S;
+            if (r + pad_t - ky >= 0 && oy >= oy0 && oy < oy1) {   // wave-uniform: other rows belong to a neighbour segment
+              const int slot = ((((ph - ky) / S) % NSLOT) + NSLOT) % NSLOT;
 #pragma unroll
               for (int kx = 0; kx < K; ++kx) {
                 const tfimm_f32x2 wv = wl[(ky * K + kx) * CPB];
 #pragma unroll
-                for (int px = 0; px < PX; ++px) acc[slot][px] = __builtin_elementwise_fma(in[px + kx], wv, acc[slot][px]);
+                for (int px = 0; px < PX; ++px) acc[slot][px] = __builtin_elementwise_fma(in[px * S + kx], wv, acc[slot][px]);
               }
             }
           }
         }
-        // output row r + pad_t - (K - 1) received its last contribution (ky = K - 1): slot ph
-        const int oyd = r + pad_t - (K - 1);
-        if (oyd >= oy0 && oyd < oy1) {
-          bf16_t* yrow = y + ((size_t)((size_t)b * OH + oyd) * OW) * C + c0;
+        // the output row whose LAST contribution (ky = K - 1) came from this input row is complete
+        if (((ph % S) == ((K - 1) % S))) {
+          constexpr int dslot_dummy = 0; (void)dslot_dummy;
+          const int dslot = ((((ph - (K - 1)) / S) % NSLOT) + NSLOT) % NSLOT;
+          const int oyd = (r + pad_t - (K - 1)) / S;
+          if (r + pad_t - (K - 1) >= 0 && oyd >= oy0 && oyd < oy1) {
+            bf16_t* yrow = y + ((size_t)((size_t)b * OH + oyd) * OW) * C + c0;
 #pragma unroll
-          for (int px = 0; px < PX; ++px) {
-            const float v0 = act1(acc[ph][px].x, actp), v1 = act1(acc[ph][px].y, actp);
-            const uint32_t pk = pack_bf2(v0, v1);
-            if (ox0 + px < OW) {
-              *reinterpret_cast<uint32_t*>(yrow + (size_t)(ox0 + px) * C) = pk;
-              // the squeeze sees the stored (bf16-rounded) activations
-              tot += tfimm_f32x2{__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)};
+            for (int px = 0; px < PX; ++px) {
+              const float v0 = act1(acc[dslot][px].x, actp), v1 = act1(acc[dslot][px].y, actp);
+              const uint32_t pk = pack_bf2(v0, v1);
+              if (ox0 + px < OW) {
+                *reinterpret_cast<uint32_t*>(yrow + (size_t)(ox0 + px) * C) = pk;
+                // the squeeze sees the stored (bf16-rounded) activations
+                tot += tfimm_f32x2{__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)};
+              }
             }
           }
-        }
 #pragma unroll
-        for (int px = 0; px < PX; ++px) acc[ph][px] = bias2;
+          for (int px = 0; px < PX; ++px) acc[dslot][px] = bias2;
+        }
       }
     }
   }
@@ -868,7 +696,7 @@ __global__ void __launch_bounds__(256) dwconv_rows_kernel(const bf16_t* __restri
   }
 }
 
-template <int K>
+template <int K, int S>
 static int launch_dwconv_rows(const bf16_t* x, const float* w, const float* bias, bf16_t* y, float* sum_out, int B, int H,
                               int W, int C, int pad_t, int pad_l, int OH, int OW, int act, hipStream_t st) {
   constexpr int PX = 4;
@@ -877,7 +705,7 @@ static int launch_dwconv_rows(const bf16_t* x, const float* w, const float* bias
   const int CPB = dw_rows_pairs_per_block(cps, sx), SPB = 256 / CPB;
   const int ctiles = (cps + CPB - 1) / CPB;
   const int sgroups = (sx + SPB - 1) / SPB;
-  // row segments cost K - 1 halo rows each: split only until every CU has its three resident workgroups
+  // row segments cost K - S halo rows each: split only until every CU has its three resident workgroups
   int nseg = 1;
   while (OH / (nseg + 1) >= 14 && (int64_t)B * ctiles * sgroups * nseg < 256 * 3) ++nseg;
   const int rows_per_seg = (OH + nseg - 1) / nseg;
@@ -887,39 +715,14 @@ static int launch_dwconv_rows(const bf16_t* x, const float* w, const float* bias
   const size_t lds = (size_t)(K * K + 1) * CPB * sizeof(tfimm_f32x2);
   static bool attr_done = false;
   if (!attr_done) {
-    TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)dwconv_rows_kernel<K, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)dwconv_rows_kernel<K, S, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     attr_done = true;
   }
-  TFIMM_LAUNCH((dwconv_rows_kernel<K, PX>), dim3((unsigned)gx, (unsigned)B), dim3(256), lds, st, x, w, bias, y, sum_out, H, W, C,
+  TFIMM_LAUNCH((dwconv_rows_kernel<K, S, PX>), dim3((unsigned)gx, (unsigned)B), dim3(256), lds, st, x, w, bias, y, sum_out, H, W, C,
                pad_t, pad_l, OH, OW, act, rows_per_seg, nseg, CPB);
   return 0;
 }
 
-template <int K, int S, int PX, int CV>
-static int launch_dwconv_march(const bf16_t* x, const float* w, const float* bias, bf16_t* y, float* sum_out, int B,
-                               int H, int W, int C, int pad_t, int pad_l, int OH, int OW, int act, hipStream_t st) {
-  const int cgs = C / CV;
-  const int CGB = cgs < 256 / CV ? cgs : 256 / CV, SPB = 256 / CGB;
-  const int ctiles = (cgs + CGB - 1) / CGB;
-  const int sx = (OW + PX - 1) / PX;
-  // split the rows into segments until the grid holds enough threads to fill the chip a few times over
-  const int64_t target = (int64_t)256 * 6 * 256;                     // threads wanted in flight
-  int nseg = 1;
-  while (nseg < OH / 8 && (int64_t)B * ctiles * CGB * sx * nseg < target) ++nseg;
-  const int rows_per_seg = (OH + nseg - 1) / nseg;
-  nseg = (OH + rows_per_seg - 1) / rows_per_seg;
-  const int sblks = (sx * nseg + SPB - 1) / SPB;
-  const size_t lds = ((size_t)K * K * 256 + 256) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)dwconv_march_kernel<K, S, PX, CV>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    attr_done = true;
-  }
-  TFIMM_LAUNCH((dwconv_march_kernel<K, S, PX, CV>), dim3((unsigned)(ctiles * sblks), (unsigned)B), dim3(256), lds, st,
-               x, w, bias, y, sum_out, H, W, C, pad_t, pad_l, OH, OW, act, rows_per_seg, nseg);
-  return 0;
-}
 
 template <int K, int S>
 static int launch_dwconv_strip(const bf16_t* x, const float* w, const float* bias, bf16_t* y, float* sum_out, int B,
@@ -1231,25 +1034,18 @@ extern "C" int tfimm_hip_dwconv(const void* x, const float* w, const float* bias
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (C % 8 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0) &&
                    (((uintptr_t)w & 15) == 0);
-  const bool vec4 = (C % 4 == 0) && (((uintptr_t)x & 7) == 0) && (((uintptr_t)y & 7) == 0);
-  static int use_march = -1;
-  if (use_march < 0) {
-    const char* e = getenv("TFIMM_DW_NO_MARCH");
-    use_march = (e && e[0] == '1') ? 0 : 1;
+  static int use_rows = -1;
+  if (use_rows < 0) {
+    const char* e = getenv("TFIMM_DW_NO_ROWS");
+    use_rows = (e && e[0] == '1') ? 0 : 1;
   }
-  if (use_march && stride == 1 && (k == 3 || k == 5 || k == 7) && (C % 2) == 0 && (((uintptr_t)x | (uintptr_t)y) & 3) == 0 && B <= 65535) {
-    // row-stationary kernel: every stride-1 layer (k = 3 measured 10-35 % faster than the marching kernel too)
-    if (k == 3) return launch_dwconv_rows<3>((const bf16_t*)x, w, bias, (bf16_t*)y, sum_out, B, H, W, C, pad_t, pad_l, OH, OW, act, st);
-    if (k == 5) return launch_dwconv_rows<5>((const bf16_t*)x, w, bias, (bf16_t*)y, sum_out, B, H, W, C, pad_t, pad_l, OH, OW, act, st);
-    return launch_dwconv_rows<7>((const bf16_t*)x, w, bias, (bf16_t*)y, sum_out, B, H, W, C, pad_t, pad_l, OH, OW, act, st);
-  }
-  if (use_march && vec4 && B <= 65535) {
-    const bf16_t* xb = (const bf16_t*)x;
-    bf16_t* yb = (bf16_t*)y;
-    if (k == 3 && stride == 1) return launch_dwconv_march<3, 1, 4, 4>(xb, w, bias, yb, sum_out, B, H, W, C, pad_t, pad_l, OH, OW, act, st);
-    if (k == 3 && stride == 2) return launch_dwconv_march<3, 2, 4, 4>(xb, w, bias, yb, sum_out, B, H, W, C, pad_t, pad_l, OH, OW, act, st);
-    if (k == 5 && stride == 1) return launch_dwconv_march<5, 1, 4, 2>(xb, w, bias, yb, sum_out, B, H, W, C, pad_t, pad_l, OH, OW, act, st);
-    if (k == 5 && stride == 2) return launch_dwconv_march<5, 2, 2, 2>(xb, w, bias, yb, sum_out, B, H, W, C, pad_t, pad_l, OH, OW, act, st);
+  if (use_rows && ((stride == 1 && (k == 3 || k == 5 || k == 7)) || (stride == 2 && (k == 3 || k == 5))) && (C % 2) == 0 && (((uintptr_t)x | (uintptr_t)y) & 3) == 0 && B <= 65535) {
+    // row-stationary kernel (an earlier sliding-window "marching" kernel measured 10-35 % slower on every shape)
+    if (stride == 2 && k == 3) return launch_dwconv_rows<3, 2>((const bf16_t*)x, w, bias, (bf16_t*)y, sum_out, B, H, W, C, pad_t, pad_l, OH, OW, act, st);
+    if (stride == 2) return launch_dwconv_rows<5, 2>((const bf16_t*)x, w, bias, (bf16_t*)y, sum_out, B, H, W, C, pad_t, pad_l, OH, OW, act, st);
+    if (k == 3) return launch_dwconv_rows<3, 1>((const bf16_t*)x, w, bias, (bf16_t*)y, sum_out, B, H, W, C, pad_t, pad_l, OH, OW, act, st);
+    if (k == 5) return launch_dwconv_rows<5, 1>((const bf16_t*)x, w, bias, (bf16_t*)y, sum_out, B, H, W, C, pad_t, pad_l, OH, OW, act, st);
+    return launch_dwconv_rows<7, 1>((const bf16_t*)x, w, bias, (bf16_t*)y, sum_out, B, H, W, C, pad_t, pad_l, OH, OW, act, st);
   }
   if (vec && C <= 8192 && B <= 65535) {
     const bf16_t* xb = (const bf16_t*)x;

@@ -598,6 +598,8 @@ CASES["dwconv_k7_p3_56_c96_segments"] = lambda: _dw_case(2, 56, 56, 96, 7, 1, 3,
 CASES["dwconv_k7_p3_7x7_c768"] = lambda: _dw_case(3, 7, 7, 768, 7, 1, 3, "", 99)               # image smaller than the halo, 3 channel tiles
 CASES["dwconv_k7_p3_odd_30x23_c10_gelu"] = lambda: _dw_case(2, 30, 23, 10, 7, 1, 3, "gelu", 100)   # 5 channel pairs, ragged strips, activation
 CASES["dwconv_k7_p3_c12_sums"] = lambda: _dw_case(2, 9, 9, 16, 7, 1, 3, "swish", 101)          # squeeze requested: strip kernel
+CASES["dwconv_k3_s2_p1_odd_c24_segments"] = lambda: _dw_case(2, 61, 45, 24, 3, 2, 1, "relu6", 107)   # symmetric padding, odd sizes
+CASES["dwconv_k5_s2_same_95_c192"] = lambda: _dw_case(2, 95, 95, 192, 5, 2, "same", "swish", 108)
 CASES["dwconv_k3_p1_generic_c6"] = lambda: _dw_case(2, 8, 8, 6, 3, 1, 1, "relu", 95)
 
 
