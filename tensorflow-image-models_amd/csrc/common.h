@@ -140,6 +140,25 @@ __device__ __forceinline__ void act8(float* v, const ActParams& q) {
   }
 }
 
+// exact-erf GELU on a pair: same formula as gelu_erf, polynomial and products as packed instructions (the two
+// transcendentals per element stay scalar -- there is no packed v_exp / v_rcp)
+__device__ __forceinline__ tfimm_f32x2 gelu_erf2(tfimm_f32x2 v) {
+  const tfimm_f32x2 xx = v * 0.70710678118654752f;
+  const tfimm_f32x2 ax = {fabsf(xx.x), fabsf(xx.y)};
+  const tfimm_f32x2 d = 1.f + 0.3275911f * ax;
+  const tfimm_f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  tfimm_f32x2 poly = tfimm_f32x2{1.061405429f, 1.061405429f};
+  poly = poly * t - 1.453152027f;
+  poly = poly * t + 1.421413741f;
+  poly = poly * t - 0.284496736f;
+  poly = poly * t + 0.254829592f;
+  const tfimm_f32x2 q = ax * ax * (-1.4426950408889634f);     // exp(-ax^2) = exp2(-ax^2 * log2 e)
+  const tfimm_f32x2 e = {__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+  const tfimm_f32x2 erfa = 1.f - poly * t * e;
+  const tfimm_f32x2 erfs = {copysignf(erfa.x, xx.x), copysignf(erfa.y, xx.y)};
+  return 0.5f * v * (1.f + erfs);
+}
+
 // Same on four packed pairs (v_pk_* arithmetic, v_med3_f32 clamp); every class is a wave-uniform
 // branch, so an epilogue pays only for the activation it has.
 __device__ __forceinline__ void act8p(tfimm_f32x2* v, const ActParams& q) {
@@ -154,18 +173,16 @@ __device__ __forceinline__ void act8p(tfimm_f32x2* v, const ActParams& q) {
     asm volatile("");
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      tfimm_f32x2 sg;
-      sg.x = __builtin_amdgcn_rcpf(1.f + __expf(-q.k * v[e].x));
-      sg.y = __builtin_amdgcn_rcpf(1.f + __expf(-q.k * v[e].y));
+      const tfimm_f32x2 z = v[e] * (-q.k * 1.4426950408889634f);          // exp(-k v) = exp2(-k v log2 e)
+      const tfimm_f32x2 en = {__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)};
+      const tfimm_f32x2 dn = 1.f + en;
+      const tfimm_f32x2 sg = {__builtin_amdgcn_rcpf(dn.x), __builtin_amdgcn_rcpf(dn.y)};
       v[e] = q.a * v[e] * sg + (q.b * sg + q.c);
     }
   } else if (q.cls == 2) {
     asm volatile("");
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[e].x = gelu_erf(v[e].x);
-      v[e].y = gelu_erf(v[e].y);
-    }
+    for (int e = 0; e < 4; ++e) v[e] = gelu_erf2(v[e]);
   }
 }
 // eight bf16 (one 16-byte row segment) -> four fp32 pairs
