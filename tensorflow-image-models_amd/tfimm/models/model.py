@@ -10,6 +10,7 @@ libtfimm_hip.so.  Subclasses provide
     inventory a Keras build would create, and
   * ``lower(b, H, W, features)``: trace the forward pass into a layer program.
 """
+import os
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
@@ -69,6 +70,9 @@ class Model:
         self._weights: Dict[str, np.ndarray] = winit.initialize(self._specs, mode=init, seed=seed)
         self._programs: Dict[tuple, Program] = {}
         self._plans: Dict[tuple, object] = {}
+        #: hipGraph recordings of plans that have been used more than once: (plan key, input dtype) -> CapturedPlan
+        self._captured: Dict[tuple, object] = {}
+        self._plan_uses: Dict[tuple, int] = {}
         #: images per kernel launch sequence; larger batches are processed in chunks so
         #: producer->consumer activations stay inside the 256 MiB Infinity Cache.
         self.micro_batch: Optional[int] = None
@@ -117,6 +121,8 @@ class Model:
                 raise KeyError(f"{self.name}: missing weights {missing[:5]}...")
         self._programs.clear()
         self._plans.clear()
+        self._captured.clear()
+        self._plan_uses.clear()
 
     def save_weights(self, path: str):
         np.savez(path, **self._weights)
@@ -175,7 +181,21 @@ class Model:
             if plan is None:
                 plan = prog.make_plan(nb)
                 self._plans[key] = plan
-            plan.run(xd[start:start + nb])
+            chunk = xd[start:start + nb]
+            # The first forward of a (shape, dtype) launches its ~100 kernels one ctypes call at a time; from the
+            # second on the whole layer program is one hipGraphLaunch on a recording made then (TFIMM_NO_GRAPH=1
+            # keeps launching eagerly).  The recording reads a private input buffer, refreshed by a device copy.
+            gkey = key + (str(chunk.dtype),)
+            cap = self._captured.get(gkey)
+            if cap is None and self._plan_uses.get(gkey, 0) >= 1 and os.environ.get("TFIMM_NO_GRAPH", "0") != "1":
+                cap = plan.capture(chunk.clone())
+                self._captured[gkey] = cap
+            self._plan_uses[gkey] = self._plan_uses.get(gkey, 0) + 1
+            if cap is not None:
+                cap.static_input.copy_(chunk)
+                cap.replay()
+            else:
+                plan.run(chunk)
             for name, t in prog.outputs.items():
                 # plans own their buffers and reuse them on the next call: hand out copies
                 results[name].append(plan.tensor_view(t).clone())

@@ -67,6 +67,29 @@ def test_interpolate_input(name, size):
     assert r["logits"] <= mc.TOL_LOGITS, r
 
 
+def test_graph_replay_matches_eager_launches():
+    """model(x): first call launches eagerly, later calls replay a hipGraph of the same plan on a private input
+    buffer -- same bits, also for new input values and after set_weights()."""
+    import tfimm
+    from tfimm.utils.init import synthetic_weights
+    m = tfimm.create_model("resnet50_mini_test_model")
+    m.set_weights(synthetic_weights(m))
+    x1, x2 = mc.make_input(m.cfg, 3, seed=1), mc.make_input(m.cfg, 3, seed=2)
+    eager1 = m(x1).numpy()                 # eager
+    replay1 = m(x1).numpy()                # records, then replays
+    replay2 = m(x2).numpy()
+    replay1b = m(x1).numpy()
+    assert m._captured, "second call should have recorded a graph"
+    assert np.array_equal(eager1, replay1) and np.array_equal(eager1, replay1b)
+    assert not np.array_equal(replay1, replay2)
+    m.set_weights(synthetic_weights(m, 7))
+    assert not m._captured
+    again = m(x1).numpy()
+    assert not np.array_equal(again, eager1)
+    feats = m(x1, return_features=True)[1]      # another program (features): its own plan and recording
+    assert "logits" in feats or len(feats) > 0
+
+
 def test_micro_batch_equals_full_batch():
     import tfimm
     from tfimm.utils.init import synthetic_weights
