@@ -253,24 +253,26 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       // vector epilogue: whole 16-byte groups per lane on aligned rows
       const int vi = ((d.N % 8) == 0 && !d.out_f32 && g.out_vec16 && (!d.residual || g.res_vec16) &&
                       (d.res_mod == 0 || d.res_mod >= 128) && (d.remap_in == 0 || d.remap_in >= 128)) ? 1 : 0;
+      // epilogue flavour: 0 catch-all, 1 vector, 2 vector without residual (arithmetic in the accumulator layout)
+      const int ei = vi ? (d.residual ? 1 : 2) : 0;
       static int occ[TFIMM_GEMM_STREAM_NUM_TILES][2] = {};
-      static bool ready[2][2] = {{false, false}, {false, false}};
-      if (!ready[fi][vi]) {
+      static bool ready[2][3] = {};
+      if (!ready[fi][ei]) {
         for (int i = 0; i < TFIMM_GEMM_STREAM_NUM_TILES; ++i) {
           const StreamTileCfg* t = stream_tile_table(i);
-          TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)t->fn[fi][vi], hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_bytes));
+          TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)t->fn[fi][ei], hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_bytes));
           int nb = 0;
-          TFIMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)t->fn[fi][vi], t->threads, (size_t)t->lds_bytes));
+          TFIMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)t->fn[fi][ei], t->threads, (size_t)t->lds_bytes));
           nb = nb < 1 ? 1 : (nb > 4 ? 4 : nb);
           if (occ[i][fi] == 0 || nb < occ[i][fi]) occ[i][fi] = nb;
         }
-        ready[fi][vi] = true;
+        ready[fi][ei] = true;
       }
       int occ_f[TFIMM_GEMM_STREAM_NUM_TILES];
       for (int i = 0; i < TFIMM_GEMM_STREAM_NUM_TILES; ++i) occ_f[i] = occ[i][fi];
       int ti = pick_stream_tile(d, occ_f);
       const StreamTileCfg* t = stream_tile_table(ti);
-      if (scale && !t->fn_scale[vi]) {   // the deep-ring tile has no SE-gate flavour
+      if (scale && !t->fn_scale[ei]) {   // the deep-ring tile has no SE-gate flavour
         ti = 0;
         t = stream_tile_table(ti);
       }
@@ -303,7 +305,7 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       if (grid > need) grid = need;
       ga.s_bytes = 0; ga.s_slots = ga.s_stride = ga.s_pieces = 0;
       if (!scale) {
-        TFIMM_LAUNCH(t->fn[fi][vi], dim3((unsigned)grid), dim3(t->threads), (size_t)t->lds_bytes, (hipStream_t)stream, ga);
+        TFIMM_LAUNCH(t->fn[fi][ei], dim3((unsigned)grid), dim3(t->threads), (size_t)t->lds_bytes, (hipStream_t)stream, ga);
         return 0;
       }
       // SE gate on A: the gate rows of the images a tile touches ride in LDS next to the operand ring (two buffers)
@@ -315,17 +317,17 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       ga.s_pieces = (int)cdiv64((int64_t)ga.s_slots * (ga.s_stride / 256), nw);
       const size_t lds = (size_t)t->lds_bytes + (size_t)2 * ga.s_pieces * nw * 1024;
       if (lds <= 160 * 1024 && nimg * d.K * 4 <= 0x7fffff00LL) {
-        static bool scale_attr[TFIMM_GEMM_STREAM_NUM_TILES][2] = {};
-        if (!scale_attr[ti][vi]) {
-          TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)t->fn_scale[vi], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          scale_attr[ti][vi] = true;
+        static bool scale_attr[TFIMM_GEMM_STREAM_NUM_TILES][3] = {};
+        if (!scale_attr[ti][ei]) {
+          TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)t->fn_scale[ei], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          scale_attr[ti][ei] = true;
         }
         // resident workgroups per CU with the gate buffers counted in
         int occ_s = (int)((160 * 1024) / lds);
         occ_s = occ_s < 1 ? 1 : (occ_s > occ_f[ti] ? occ_f[ti] : occ_s);
         grid = ((int64_t)num_cu() * occ_s + 7) / 8 * 8;
         if (grid > need) grid = need;
-        TFIMM_LAUNCH(t->fn_scale[vi], dim3((unsigned)grid), dim3(t->threads), lds, (hipStream_t)stream, ga);
+        TFIMM_LAUNCH(t->fn_scale[ei], dim3((unsigned)grid), dim3(t->threads), lds, (hipStream_t)stream, ga);
         return 0;
       }
       // does not fit: the register-staged kernel below

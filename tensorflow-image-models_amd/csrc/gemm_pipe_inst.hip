@@ -6,8 +6,8 @@ namespace tfimm_gemm {
 
 extern "C" __attribute__((visibility("hidden"))) const StreamTileCfg tfimm_gemm_stream_tile_7 = {
     256, 256, 512, 2 * (256 + 256) * 128,
-    {{gemm_stream_kernel<256, 256, 2, 4, K_DENSE, false>, gemm_pipe_kernel<K_DENSE>},
-     {gemm_stream_kernel<256, 256, 2, 4, K_CONV, false>, gemm_pipe_kernel<K_CONV>}},
-    {nullptr, nullptr}};
+    {{gemm_stream_kernel<256, 256, 2, 4, K_DENSE, false>, gemm_pipe_kernel<K_DENSE>, gemm_pipe_kernel<K_DENSE>},
+     {gemm_stream_kernel<256, 256, 2, 4, K_CONV, false>, gemm_pipe_kernel<K_CONV>, gemm_pipe_kernel<K_CONV>}},
+    {nullptr, nullptr, nullptr}};
 
 }  // namespace tfimm_gemm

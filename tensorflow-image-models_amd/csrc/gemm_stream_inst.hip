@@ -22,8 +22,11 @@ using G = StreamGeom<T::bm, T::bn, T::wm, T::wn>;
 
 extern "C" __attribute__((visibility("hidden"))) const StreamTileCfg TFIMM_CAT(tfimm_gemm_stream_tile_, TILE_ID) = {
     T::bm, T::bn, T::wm* T::wn * 64, G::LDS_BYTES,
-    {{gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_DENSE, false>, gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_DENSE, true>},
-     {gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_CONV, false>, gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_CONV, true>}},
-    {gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_DENSE, false, true>, gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_DENSE, true, true>}};
+    {{gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_DENSE, false>, gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_DENSE, true>,
+      gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_DENSE, true, false, true>},
+     {gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_CONV, false>, gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_CONV, true>,
+      gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_CONV, true, false, true>}},
+    {gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_DENSE, false, true>, gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_DENSE, true, true>,
+     gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_DENSE, true, true, true>}};
 
 }  // namespace tfimm_gemm

@@ -66,7 +66,7 @@ struct StreamGeom {
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit in LDS");
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int KMODE, bool VEC, bool SCALE = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KMODE, bool VEC, bool SCALE = false, bool NORES = false>
 __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(const GemmStreamArgs pa) {
   using G = StreamGeom<BM, BN, WAVES_M, WAVES_N>;
   const GemmArgs& p = pa.g;
@@ -256,6 +256,10 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   const int e_row = lane / LPR;
   const int e_c8 = lane % LPR;
   const bool has_res = p.residual != nullptr;
+  // Without a residual the whole epilogue arithmetic can run on the accumulators BEFORE the transpose through
+  // LDS: the staged block is bf16 (half the LDS write traffic, which is the slow direction at ~80 B/clk) and the
+  // read-back feeds the stores directly -- no VALU work between LDS and the store.
+  constexpr bool fast_epi = VEC && NORES;          // a kernel flavour of its own: both epilogues in one kernel spill
 
   // ---- prime the pipeline
   int iss_tile = t_first, iss_kt = 1;
@@ -294,9 +298,19 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
     const unsigned ldc2 = (unsigned)p.ldc * 2u, ldr2 = (unsigned)p.ldr * 2u;
     const unsigned out_wrap = p.remap_in > 0 ? (unsigned)(p.remap_out - p.remap_in) * ldc2 : 0u;
     const unsigned res_wrap = p.res_mod > 0 ? (unsigned)p.res_mod * ldr2 : 0u;
+    // fast epilogue: lane l < WTN/4 fetches bias quad l of the wave's columns here (a load issued in the epilogue would
+    // have to wait behind the next step's DMA), parks it in LDS there
+    f32x4 bfast = {0.f, 0.f, 0.f, 0.f};
+    if (fast_epi && lane < WTN / 4) {
+      const int n = n0 + wn * WTN + lane * 4;
+      if (p.bias && n < p.N) {
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+        bfast = f32x4{b4.x, b4.y, b4.z, b4.w};
+      }
+    }
     if (VEC) {
       const bool col_ok = e_n < p.N;   // N % 8 == 0: all 8 channels or none
-      if (p.bias && col_ok) {
+      if (!fast_epi && p.bias && col_ok) {
         const float4 b0 = *reinterpret_cast<const float4*>(p.bias + e_n);
         const float4 b1 = *reinterpret_cast<const float4*>(p.bias + e_n + 4);
         bias2[0] = tfimm_f32x2{b0.x, b0.y}; bias2[1] = tfimm_f32x2{b0.z, b0.w};
@@ -360,7 +374,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
       asm volatile("" ::: "memory");                     //     epilogue block in it) is free again
       // first residual rows of THIS tile: requested ahead of the next step's DMA, so the wait for
       // them in the epilogue leaves that DMA in flight
-      if (VEC && last) {
+      if (VEC && last && !fast_epi) {
 #pragma unroll
         for (int it = 0; it < ITS; ++it) load_res1(0, it);
       }
@@ -427,6 +441,94 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
     }
     // a wave whose 32/64 columns all lie beyond N has nothing to store (ragged N: the last column tile); such a
     // tile is never `interior`, so the counted wait of the next step does not expect its stores
+    if (fast_epi) {
+      if (n0 + wn * WTN < p.N) {
+        constexpr int CPR = WTN / 8;                 // 16-byte chunks per staged bf16 row
+        char* const sE16 = reinterpret_cast<char*>(sEw);
+        // in the accumulator layout a lane owns channels j*32 + q*8 + fhi*4 .. +3 of its rows.  The wave's WTN bias
+        // values go through the unused half of its staging block (the staged rows are bf16 here), read back as
+        // quads where they are needed: holding all 8 quads in registers spills the main loop
+        float* const bs = reinterpret_cast<float*>(sE16 + 32 * WTN * 2);
+        if (lane < WTN / 4) {
+          const unsigned baddr = (unsigned)(size_t)(lds_ptr_t)(bs + lane * 4);
+          asm volatile("ds_write_b128 %0, %1" ::"v"(baddr), "v"(bfast) : "memory");
+        }
+        // every LDS read of this epilogue is an explicit ds_read: before an LDS access it can see, hipcc waits for ALL
+        // outstanding LDS-DMA (vmcnt(0)), i.e. for the next step's prefetch
+        static_assert(TN == 1 || TN == 2, "fast epilogue: 32 or 64 columns per wave");
+        u32x4 bq[TN * 4];
+        {
+          const unsigned ba = (unsigned)(size_t)(lds_ptr_t)(bs + fhi * 4);
+          if (TN == 2) {
+            asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:32\n\tds_read_b128 %2, %8 offset:64\n\t"
+                         "ds_read_b128 %3, %8 offset:96\n\tds_read_b128 %4, %8 offset:128\n\tds_read_b128 %5, %8 offset:160\n\t"
+                         "ds_read_b128 %6, %8 offset:192\n\tds_read_b128 %7, %8 offset:224\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(bq[0]), "=&v"(bq[1]), "=&v"(bq[2]), "=&v"(bq[3]), "=&v"(bq[TN * 4 - 4]), "=&v"(bq[TN * 4 - 3]),
+                           "=&v"(bq[TN * 4 - 2]), "=&v"(bq[TN * 4 - 1])
+                         : "v"(ba) : "memory");
+          } else {
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\t"
+                         "ds_read_b128 %3, %4 offset:96\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(bq[0]), "=&v"(bq[1]), "=&v"(bq[2]), "=&v"(bq[3]) : "v"(ba) : "memory");
+          }
+        }
+        const int wsw = CPR == 8 ? ((frow >> 1) & 7) : ((frow >> 2) & 3);    // chunk swizzle of this lane's row
+        unsigned rb_addr[ITS];
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+          const int pr = it * RPI + e_row;
+          const int rsw = CPR == 8 ? ((pr >> 1) & 7) : ((pr >> 2) & 3);
+          rb_addr[it] = (unsigned)(size_t)(lds_ptr_t)(sE16 + pr * (WTN * 2) + ((e_c8 ^ rsw) * 16));
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          if (TN == 2) {
+            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[i][0]), "+v"(acc[i][TN - 1]));
+          } else {
+            asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[i][0]));
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+              tfimm_f32x2 v[4];
+#pragma unroll
+              for (int h2 = 0; h2 < 2; ++h2) {
+                const int q = q2 * 2 + h2;
+                const f32x4 b4 = __builtin_bit_cast(f32x4, bq[j * 4 + q]);
+                v[h2 * 2 + 0] = tfimm_f32x2{acc[i][j][q * 4 + 0] + b4[0], acc[i][j][q * 4 + 1] + b4[1]};
+                v[h2 * 2 + 1] = tfimm_f32x2{acc[i][j][q * 4 + 2] + b4[2], acc[i][j][q * 4 + 3] + b4[3]};
+              }
+              act8p(v, actp);
+              const uint4 pk = pack8p(v);
+#pragma unroll
+              for (int h2 = 0; h2 < 2; ++h2) {
+                const int chunk = j * 4 + q2 * 2 + h2;
+                const unsigned addr = (unsigned)(size_t)(lds_ptr_t)(sE16 + frow * (WTN * 2) + ((chunk ^ wsw) * 16) + fhi * 8);
+                const uint2 w2 = h2 ? make_uint2(pk.z, pk.w) : make_uint2(pk.x, pk.y);
+                asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(w2) : "memory");
+              }
+            }
+          u32x4 o16[ITS];
+          if (ITS == 4) {
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(o16[0]), "=&v"(o16[1]), "=&v"(o16[ITS - 2]), "=&v"(o16[ITS - 1])
+                         : "v"(rb_addr[0]), "v"(rb_addr[1]), "v"(rb_addr[ITS - 2]), "v"(rb_addr[ITS - 1]) : "memory");
+          } else {
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(o16[0]), "=&v"(o16[1]) : "v"(rb_addr[0]), "v"(rb_addr[1]) : "memory");
+          }
+#pragma unroll
+          for (int it = 0; it < ITS; ++it) {
+            const int d = i * 32 + it * RPI;
+            unsigned off = out_off0 + (unsigned)d * ldc2;
+            off += (or0 + d >= remap_eff) ? out_wrap : 0u;
+            __builtin_amdgcn_raw_buffer_store_b128(o16[it], rsrc_o, (int)off, 0, 0);
+          }
+        }
+      }
+    } else
     if (!(VEC && n0 + wn * WTN >= p.N))
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -456,12 +558,29 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
       if (i == 0) stamp();
       if (VEC) {
         // read back row-contiguous: lane handles 8 consecutive channels of one row
+        // (explicit ds_reads, two iterations per wait: an LDS read hipcc can see waits for the next step's DMA)
+        static_assert(ITS % 2 == 0, "read-back iterations come in pairs");
 #pragma unroll
-        for (int it = 0; it < ITS; ++it) {
-          const int pr = it * RPI + e_row;
-          const float4 lo = *reinterpret_cast<const float4*>(&sEw[pr * WTN + epi_slot(pr, 2 * e_c8) * 4]);
-          const float4 hi = *reinterpret_cast<const float4*>(&sEw[pr * WTN + epi_slot(pr, 2 * e_c8 + 1) * 4]);
-          tfimm_f32x2 v[4] = {{lo.x, lo.y}, {lo.z, lo.w}, {hi.x, hi.y}, {hi.z, hi.w}};
+        for (int ip = 0; ip < ITS; ip += 2) {
+        f32x4 st[4];
+        {
+          unsigned ra[4];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int pr = (ip + u) * RPI + e_row;
+            ra[2 * u] = (unsigned)(size_t)(lds_ptr_t)(&sEw[pr * WTN + epi_slot(pr, 2 * e_c8) * 4]);
+            ra[2 * u + 1] = (unsigned)(size_t)(lds_ptr_t)(&sEw[pr * WTN + epi_slot(pr, 2 * e_c8 + 1) * 4]);
+          }
+          asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\t"
+                       "s_waitcnt lgkmcnt(0)"
+                       : "=&v"(st[0]), "=&v"(st[1]), "=&v"(st[2]), "=&v"(st[3])
+                       : "v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]) : "memory");
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int it = ip + u;
+          const f32x4 lo = st[2 * u], hi = st[2 * u + 1];
+          tfimm_f32x2 v[4] = {{lo[0], lo[1]}, {lo[2], lo[3]}, {hi[0], hi[1]}, {hi[2], hi[3]}};
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += bias2[e];
           const uint4 rraw = rres[it];
@@ -490,6 +609,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
           // (default cache policy: non-temporal stores are 3-8 % faster for this launch alone but the
           // next layer then misses L2/MALL on what it reads first -- ResNet-50 end to end -1.5 %)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pack8p(v)), rsrc_o, (int)off, 0, 0);
+        }
         }
       } else {
         // catch-all: element loop over the staged block (the wave's own LDS, in order -> no barrier)
@@ -523,8 +643,8 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
 
 struct StreamTileCfg {
   int bm, bn, threads, lds_bytes;
-  gemm_stream_fn fn[2][2];  // [K_DENSE, K_CONV][catch-all, VEC]
-  gemm_stream_fn fn_scale[2];  // K_DENSE + SE gate on A: [catch-all, VEC] (null: not built for this tile)
+  gemm_stream_fn fn[2][3];     // [K_DENSE, K_CONV][catch-all, VEC, VEC without residual]
+  gemm_stream_fn fn_scale[3];  // K_DENSE + SE gate on A, same three epilogues (null: not built for this tile)
 };
 
 }  // namespace tfimm_gemm

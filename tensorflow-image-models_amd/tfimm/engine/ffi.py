@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtfimm_hip.so")
+# TFIMM_HIP_LIB: another build of the same library (kernel A/B comparisons); there is no non-HIP fallback
+LIB_PATH = os.environ.get("TFIMM_HIP_LIB") or os.path.join(_HERE, "libtfimm_hip.so")
 
 ACT = {
     "": 0, "linear": 0, "none": 0, None: 0,
