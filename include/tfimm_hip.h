@@ -135,6 +135,21 @@ TFIMM_API int tfimm_hip_cast_input_pad(const void* in, int in_dtype, void* out, 
                              int pad_t, int pad_b, int pad_l, int pad_r, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * tfimm_hip_preprocess_input / _pad: the two conversions above for a uint8 image with values in [0, 255], with the
+ * model's preprocessing applied on the way: out = bf16(((float)v / 255 - mean[c]) / std[c]) -- the three float32
+ * operations of create_preprocessing (models/factory.py:165-167; mean/std: utils/constants.py:3-6, tiled to c_in by
+ * the caller as in factory.py:153-163), so the result is bit-identical to preprocessing in float32 on the host
+ * followed by tfimm_hip_cast_input.  mean, std: HOST arrays of c_in floats (copied into the launch),
+ * c_in <= TFIMM_PREPROCESS_MAX_CHANNELS (<= 4 for _pad); padded channels and the border are 0.
+ * ------------------------------------------------------------------------------------- */
+#define TFIMM_PREPROCESS_MAX_CHANNELS 8
+TFIMM_API int tfimm_hip_preprocess_input(const void* in, void* out, int64_t n_pixels, int c_in, int c_out,
+                               const float* mean, const float* std, void* stream);
+TFIMM_API int tfimm_hip_preprocess_input_pad(const void* in, void* out, int B, int H, int W, int c_in,
+                                   int pad_t, int pad_b, int pad_l, int pad_r,
+                                   const float* mean, const float* std, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * tfimm_hip_layernorm: y[r][:] = (x[r][:] - mean) * rsqrt(var + eps) * gamma + beta,
  * population variance, fp32 statistics.  x row r starts at x + r*x_stride (elements),
  * y row r at y + r*y_stride.  Replaces tf.keras.layers.LayerNormalization

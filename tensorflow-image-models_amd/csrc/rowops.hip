@@ -100,6 +100,89 @@ __global__ void cast_pad4_kernel(const void* in, uint2* out, int B, int H, int W
 }
 
 // ---------------------------------------------------------------------------------------
+// preprocess_input: uint8 image -> (v / 255 - mean[c]) / std[c] -> bf16, in the layouts of the cast kernels above.
+// The three fp32 operations are the reference's (factory.py:165-167), each correctly rounded, so the result equals
+// preprocessing on the host in float32 followed by cast_input, bit for bit.
+// ---------------------------------------------------------------------------------------
+struct NormParams {
+  float mean[TFIMM_PREPROCESS_MAX_CHANNELS];
+  float std[TFIMM_PREPROCESS_MAX_CHANNELS];
+};
+
+__device__ __forceinline__ uint32_t norm_u8(uint32_t v, float mean, float std) {
+  return f2bf(((float)v / 255.0f - mean) / std);
+}
+
+__global__ void preprocess_kernel(const uint8_t* in, bf16_t* out, int64_t n_pixels, int c_in, int c_out, NormParams np) {
+  for (int64_t px = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; px < n_pixels;
+       px += (int64_t)gridDim.x * blockDim.x) {
+    bf16_t* o = out + px * c_out;
+    for (int c = 0; c < c_out; ++c) o[c] = (bf16_t)(c < c_in ? norm_u8(in[px * c_in + c], np.mean[c], np.std[c]) : 0u);
+  }
+}
+
+// The two image kernels below look the 256 possible results per channel up in LDS (each block evaluates the formula
+// once per (channel, value), 256 threads): six correctly rounded divisions per pixel would make them ALU-bound.
+__device__ __forceinline__ void build_norm_lut(uint16_t (*lut)[256], int c_in, const NormParams& np) {
+  for (int c = 0; c < 4; ++c)
+    for (int v = threadIdx.x; v < 256; v += blockDim.x)
+      lut[c][v] = c < c_in ? (uint16_t)norm_u8((uint32_t)v, np.mean[c], np.std[c]) : (uint16_t)0;
+  __syncthreads();
+}
+
+// RGB fast path: a thread converts 4 pixels = 12 input bytes (three aligned dwords) -> 32 output bytes
+__global__ void preprocess_rgb4_kernel(const uint8_t* in, uint2* out, int64_t n_pixels, NormParams np) {
+  __shared__ uint16_t lut[4][256];
+  build_norm_lut(lut, 3, np);
+  const int64_t groups = n_pixels >> 2;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(in) + g * 3;
+    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+    const uint32_t by[12] = {w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u, w0 >> 24, w1 & 255u, (w1 >> 8) & 255u,
+                             (w1 >> 16) & 255u, w1 >> 24, w2 & 255u, (w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24};
+    uint2 o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t r = lut[0][by[3 * k]], gch = lut[1][by[3 * k + 1]], b = lut[2][by[3 * k + 2]];
+      o[k] = make_uint2(r | (gch << 16), b);
+    }
+    uint4* q = reinterpret_cast<uint4*>(out + g * 4);
+    q[0] = make_uint4(o[0].x, o[0].y, o[1].x, o[1].y);
+    q[1] = make_uint4(o[2].x, o[2].y, o[3].x, o[3].y);
+  }
+  // the last n_pixels % 4 pixels
+  const int64_t px = (groups << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (px < n_pixels) {
+    const uint8_t* p = in + px * 3;
+    out[px] = make_uint2((uint32_t)lut[0][p[0]] | ((uint32_t)lut[1][p[1]] << 16), (uint32_t)lut[2][p[2]]);
+  }
+}
+
+// uint8 image -> zero-bordered 4-channel bf16 image (one thread per OUTPUT pixel); the border stays 0: the
+// reference pads the preprocessed image
+__global__ void preprocess_pad4_kernel(const uint8_t* in, uint2* out, int B, int H, int W, int c_in, int pad_t, int pad_l,
+                                       int HP, int WP, NormParams np) {
+  __shared__ uint16_t lut[4][256];
+  build_norm_lut(lut, c_in, np);
+  const int64_t total = (int64_t)B * HP * WP;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+    const int xp = (int)(id % WP);
+    const int64_t t = id / WP;
+    const int yp = (int)(t % HP);
+    const int b = (int)(t / HP);
+    const int y = yp - pad_t, x = xp - pad_l;
+    uint32_t c[4] = {0u, 0u, 0u, 0u};
+    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+      const int64_t px = ((int64_t)b * H + y) * W + x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (e < c_in) c[e] = lut[e][in[px * c_in + e]];
+    }
+    out[id] = make_uint2(c[0] | (c[1] << 16), c[2] | (c[3] << 16));
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // layernorm: one wave per row, row cached in registers (vector path) or re-read (generic)
 // ---------------------------------------------------------------------------------------
 template <int NCH>  // 16-byte chunks per lane: supports d <= NCH * 512
@@ -960,6 +1043,47 @@ extern "C" int tfimm_hip_cast_input_pad(const void* in, int in_dtype, void* out,
   const unsigned grid = grid_for((int64_t)B * HP * WP, 256);
   if (in_dtype) TFIMM_LAUNCH(cast_pad4_kernel<true>, dim3(grid), dim3(256), 0, st, in, (uint2*)out, B, H, W, c_in, pad_t, pad_l, HP, WP);
   else TFIMM_LAUNCH(cast_pad4_kernel<false>, dim3(grid), dim3(256), 0, st, in, (uint2*)out, B, H, W, c_in, pad_t, pad_l, HP, WP);
+  return 0;
+}
+
+static bool norm_params(NormParams& np, const float* mean, const float* std, int c_in) {
+  if (!mean || !std || c_in <= 0 || c_in > TFIMM_PREPROCESS_MAX_CHANNELS) return false;
+  for (int c = 0; c < TFIMM_PREPROCESS_MAX_CHANNELS; ++c) {
+    np.mean[c] = c < c_in ? mean[c] : 0.f;
+    np.std[c] = c < c_in ? std[c] : 1.f;
+    if (!(np.std[c] != 0.f)) return false;
+  }
+  return true;
+}
+
+extern "C" int tfimm_hip_preprocess_input(const void* in, void* out, int64_t n_pixels, int c_in, int c_out,
+                                          const float* mean, const float* std, void* stream) {
+  NormParams np;
+  if (!in || !out || n_pixels <= 0 || c_out < c_in || !norm_params(np, mean, std, c_in))
+    TFIMM_FAIL(TFIMM_EINVAL, "preprocess_input: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (c_in == 3 && c_out == 4 && (((uintptr_t)out & 15) == 0) && (((uintptr_t)in & 3) == 0)) {
+    const unsigned grid = grid_for((n_pixels + 3) / 4, 256);
+    TFIMM_LAUNCH(preprocess_rgb4_kernel, dim3(grid), dim3(256), 0, st, (const uint8_t*)in, (uint2*)out, n_pixels, np);
+  } else {
+    const unsigned grid = grid_for(n_pixels, 256);
+    TFIMM_LAUNCH(preprocess_kernel, dim3(grid), dim3(256), 0, st, (const uint8_t*)in, (bf16_t*)out, n_pixels, c_in, c_out, np);
+  }
+  return 0;
+}
+
+extern "C" int tfimm_hip_preprocess_input_pad(const void* in, void* out, int B, int H, int W, int c_in, int pad_t,
+                                              int pad_b, int pad_l, int pad_r, const float* mean, const float* std,
+                                              void* stream) {
+  NormParams np;
+  if (!in || !out || B <= 0 || H <= 0 || W <= 0 || c_in > 4 || pad_t < 0 || pad_b < 0 || pad_l < 0 || pad_r < 0 ||
+      ((uintptr_t)out & 7) || !norm_params(np, mean, std, c_in))
+    TFIMM_FAIL(TFIMM_EINVAL, "preprocess_input_pad: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int HP = H + pad_t + pad_b, WP = W + pad_l + pad_r;
+  const unsigned grid = grid_for((int64_t)B * HP * WP, 256);
+  TFIMM_LAUNCH(preprocess_pad4_kernel, dim3(grid), dim3(256), 0, st, (const uint8_t*)in, (uint2*)out, B, H, W, c_in, pad_t,
+               pad_l, HP, WP, np);
   return 0;
 }
 

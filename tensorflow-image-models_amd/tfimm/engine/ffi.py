@@ -67,6 +67,9 @@ SYMBOLS = {
     "tfimm_hip_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "tfimm_hip_cast_input": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp]),
     "tfimm_hip_cast_input_pad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "tfimm_hip_preprocess_input": (_i, [_vp, _vp, _i64, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
+    "tfimm_hip_preprocess_input_pad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float),
+                                            C.POINTER(C.c_float), _vp]),
     "tfimm_hip_layernorm": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i64, _i64, _f, _vp]),
     "tfimm_hip_attention": (_i, [C.POINTER(AttnDesc), _vp]),
     "tfimm_hip_talking_heads_attention": (_i, [C.POINTER(ThaDesc), _vp]),

@@ -613,8 +613,10 @@ class Plan:
                 if a["pad"] != (0, 0, 0, 0):
                     pt_, pb_, pl_, pr_ = a["pad"]
                     self._input_call = (lib.tfimm_hip_cast_input_pad, (out, B, H, W, a["c_in"], pt_, pb_, pl_, pr_))
+                    self._input_call_u8 = (lib.tfimm_hip_preprocess_input_pad, self._input_call[1])
                 else:
                     self._input_call = (lib.tfimm_hip_cast_input, (out, B * H * W, a["c_in"], a["c_out"]))
+                    self._input_call_u8 = (lib.tfimm_hip_preprocess_input, self._input_call[1])
                 self.calls.append((self._input_call[0], None))  # input pointer / dtype patched per call
             elif k == "gemm":
                 d = ffi.GemmDesc()
@@ -833,8 +835,8 @@ class Plan:
                 self._gemm_descs[gi].tile_hint = best
         return changed
 
-    def capture(self, x_dev) -> "CapturedPlan":
-        return CapturedPlan(self, x_dev)
+    def capture(self, x_dev, norm=None) -> "CapturedPlan":
+        return CapturedPlan(self, x_dev, norm)
 
     def check_marshalling(self):
         """Convert every recorded argument through the ctypes prototypes (no launch): catches
@@ -846,6 +848,13 @@ class Plan:
                 continue
             if args is None:  # cast_input: patched per call
                 args = (0, 0) + tuple(self._input_call[1])
+                c_in = self._input_patch[3]
+                u8_fn, u8_args = self._input_call_u8
+                u8_args = (0,) + tuple(u8_args) + ((C.c_float * c_in)(), (C.c_float * c_in)())
+                if len(u8_args) + 1 != len(u8_fn.argtypes):
+                    raise TypeError(f"call {i} ({u8_fn.__name__}): {len(u8_args) + 1} args for {len(u8_fn.argtypes)}")
+                for a, pt in zip(u8_args, u8_fn.argtypes):
+                    pt.from_param(a)
             protos = fn.argtypes
             if len(args) + 1 != len(protos):
                 raise TypeError(f"call {i} ({fn.__name__}): {len(args) + 1} args for {len(protos)} parameters")
@@ -855,18 +864,27 @@ class Plan:
         return n
 
     # run -------------------------------------------------------------------------------------------
-    def run(self, x_dev, stream_ptr: Optional[int] = None):
+    def run(self, x_dev, stream_ptr: Optional[int] = None, norm=None):
         """Enqueue the whole program on the current torch stream.  ``x_dev``: contiguous cuda
-        tensor (B, H, W, C) float32 or bfloat16."""
+        tensor (B, H, W, C) float32 or bfloat16 -- or uint8 with ``norm = (mean, std)`` (one float per
+        channel): the model's preprocessing then runs inside the input conversion
+        (tfimm_hip_preprocess_input)."""
         import torch
         ffi = self.ffi
         if stream_ptr is None:
             stream_ptr = torch.cuda.current_stream().cuda_stream
         st = C.c_void_p(stream_ptr)
         idx, out, npix, c_in, c_out = self._input_patch
+        if (x_dev.dtype == torch.uint8) != (norm is not None):
+            raise TypeError("uint8 input needs norm=(mean, std); float input must not pass it")
+        if norm is not None:
+            mean = (C.c_float * c_in)(*[float(v) for v in norm[0]])
+            std = (C.c_float * c_in)(*[float(v) for v in norm[1]])
         in_dtype = 1 if x_dev.dtype == torch.bfloat16 else 0
         for i, (fn, args) in enumerate(self.calls):
-            if i == idx:
+            if i == idx and norm is not None:
+                rc = self._input_call_u8[0](x_dev.data_ptr(), *self._input_call_u8[1], mean, std, st)
+            elif i == idx:
                 rc = fn(x_dev.data_ptr(), in_dtype, *self._input_call[1], st)
             elif fn == "memset":
                 ffi.check(_hip_memset_async(args[0], args[1], stream_ptr), "hipMemsetAsync")
@@ -883,17 +901,17 @@ class CapturedPlan:
     instead of ~100 ctypes calls + kernel launches.  The input pointer is baked into the graph, so
     callers either keep writing into ``static_input`` or replay on the tensor that was captured."""
 
-    def __init__(self, plan: "Plan", x_dev):
+    def __init__(self, plan: "Plan", x_dev, norm=None):
         import torch
         self.plan = plan
         self.static_input = x_dev
         # every lazy host-side initialisation (function attributes, occupancy queries) must have
         # happened before capture: run the plan once eagerly
-        plan.run(x_dev)
+        plan.run(x_dev, norm=norm)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            plan.run(x_dev)
+            plan.run(x_dev, norm=norm)       # (mean/std travel by value in the recorded launch)
 
     def replay(self):
         self.graph.replay()

@@ -73,10 +73,15 @@ def create_model(
 
 
 def create_preprocessing(model_name: str, *, in_channels: Optional[int] = None,
-                         dtype: Optional[str] = None) -> Callable:
+                         dtype: Optional[str] = None, defer: bool = False) -> Callable:
     """Function mapping [0, 255] images to model inputs: ``(img / 255 - mean) / std`` with
     mean/std tiled to ``in_channels`` (factory.py:153-169).  Works on numpy arrays and torch
-    tensors, single images and batches; returns the input's array type."""
+    tensors, single images and batches; returns the input's array type.
+
+    ``defer=True`` (not in the reference): a **uint8** image is not converted on the host but wrapped
+    in a ``DeferredInput``; ``model(pre(img))`` then evaluates the same three float32 operations inside
+    the kernel that converts the input to the engine's layout -- same bits as the host path, a quarter of
+    the input bytes.  Anything that is not uint8 is preprocessed immediately as without the flag."""
     if not is_model(model_name):
         raise ValueError(f"Unknown model: {model_name}.")
     cfg = model_config(model_name)
@@ -91,6 +96,9 @@ def create_preprocessing(model_name: str, *, in_channels: Optional[int] = None,
     mean, std = _adapt(cfg.mean), _adapt(cfg.std)
 
     def _preprocess(img):
+        if defer and getattr(img, "dtype", None) is not None and str(img.dtype).endswith("uint8"):
+            from .model import DeferredInput
+            return DeferredInput(img, mean.astype(np.float32), std.astype(np.float32))
         try:
             import torch
             if isinstance(img, torch.Tensor):

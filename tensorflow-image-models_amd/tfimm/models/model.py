@@ -57,6 +57,33 @@ class Tensor:
         return f"tfimm.Tensor(shape={self.shape}, dtype={self._t.dtype}, device={self._t.device})"
 
 
+class DeferredInput:
+    """uint8 pixels in [0, 255] plus the model's per-channel (mean, std): what
+    ``create_preprocessing(name, defer=True)`` returns for uint8 images.  ``model(x)`` consumes it directly
+    -- ``(v / 255 - mean) / std`` is evaluated by the kernel that converts the input to the engine's
+    bf16 layout (tfimm_hip_preprocess_input), so no float image is ever materialised.  ``numpy()`` gives
+    the float32 image the reference's preprocessing would have produced (models/factory.py:165-167)."""
+
+    def __init__(self, data, mean, std):
+        self.data = data
+        self.mean = tuple(float(np.float32(v)) for v in mean)
+        self.std = tuple(float(np.float32(v)) for v in std)
+
+    @property
+    def shape(self):
+        return tuple(self.data.shape)
+
+    def numpy(self) -> np.ndarray:
+        d = self.data
+        d = d.cpu().numpy() if hasattr(d, "cpu") else np.asarray(d)
+        x = d.astype(np.float32) / np.float32(255.0)
+        return (x - np.asarray(self.mean, np.float32)) / np.asarray(self.std, np.float32)
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a.astype(dtype) if dtype is not None else a
+
+
 class Model:
     cfg_class = None
     #: weights that exist in the reference as non-trainable build-time constants and are
@@ -152,6 +179,15 @@ class Model:
 
     def _to_device(self, x):
         import torch
+        if isinstance(x, DeferredInput):
+            # uint8 pixels + (mean, std): the normalisation runs inside the engine's input conversion
+            u = x.data if isinstance(x.data, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x.data))
+            if u.dim() != 4 or u.shape[-1] != self.cfg.in_channels or len(x.mean) != self.cfg.in_channels:
+                raise ValueError(f"{self.name}: expected uint8 input (B, H, W, {self.cfg.in_channels}), got shape "
+                                 f"{tuple(u.shape)} with {len(x.mean)} mean/std values")
+            if not torch.cuda.is_available():
+                raise RuntimeError("tfimm (MI355X engine) needs a ROCm GPU: no CPU execution path exists.")
+            return u.to("cuda", non_blocking=True).contiguous()
         if isinstance(x, Tensor):
             x = x.torch()
         if not isinstance(x, torch.Tensor):
@@ -169,6 +205,7 @@ class Model:
     def _run(self, x, want_features: bool):
         import torch
         xd = self._to_device(x)
+        norm = (tuple(x.mean), tuple(x.std)) if isinstance(x, DeferredInput) else None
         B, H, W, _ = xd.shape
         prog = self.program(H, W, want_features)
         mb = self.micro_batch or B
@@ -185,17 +222,17 @@ class Model:
             # The first forward of a (shape, dtype) launches its ~100 kernels one ctypes call at a time; from the
             # second on the whole layer program is one hipGraphLaunch on a recording made then (TFIMM_NO_GRAPH=1
             # keeps launching eagerly).  The recording reads a private input buffer, refreshed by a device copy.
-            gkey = key + (str(chunk.dtype),)
+            gkey = key + (str(chunk.dtype), norm)
             cap = self._captured.get(gkey)
             if cap is None and self._plan_uses.get(gkey, 0) >= 1 and os.environ.get("TFIMM_NO_GRAPH", "0") != "1":
-                cap = plan.capture(chunk.clone())
+                cap = plan.capture(chunk.clone(), norm)
                 self._captured[gkey] = cap
             self._plan_uses[gkey] = self._plan_uses.get(gkey, 0) + 1
             if cap is not None:
                 cap.static_input.copy_(chunk)
                 cap.replay()
             else:
-                plan.run(chunk)
+                plan.run(chunk, norm=norm)
             for name, t in prog.outputs.items():
                 # plans own their buffers and reuse them on the next call: hand out copies
                 results[name].append(plan.tensor_view(t).clone())

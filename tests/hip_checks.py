@@ -561,6 +561,43 @@ def _():
     return max(_err(_cpu(got), ref), _err(_cpu(gotb), ref), ok5), 1e-6
 
 
+def _preprocess_ref(u8, mean, std):
+    """create_preprocessing in float32 on the host (models/factory.py:165-167), then the bf16 rounding of cast_input."""
+    x = u8.astype(np.float32) / np.float32(255.0)
+    return _bf((x - np.asarray(mean, np.float32)) / np.asarray(std, np.float32))
+
+
+@case("preprocess_input_u8")
+def _():
+    """uint8 -> normalised bf16: RGB fast path (pixel counts with every remainder mod 4), generic channel counts, and
+    the zero-bordered variant; bit-exact against the host formula (every uint8 value occurs)."""
+    import hip_ops as H
+    r = _rng(89)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    worst = 0.0
+    for shape in [(2, 16, 16, 3), (1, 5, 7, 3), (3, 3, 3, 3), (1, 1, 2, 3)]:
+        u = r.integers(0, 256, shape, dtype=np.uint8)
+        u.reshape(-1)[:256] = np.arange(256, dtype=np.uint8)[: u.size]
+        got = _cpu(H.preprocess_input(torch.from_numpy(u).to(H.DEV), 4, mean, std))
+        ref = np.concatenate([_preprocess_ref(u, mean, std), np.zeros(shape[:3] + (1,), np.float32)], -1)
+        worst = max(worst, float(np.abs(got - ref).max()))
+    for cin, cout in [(1, 8), (5, 8), (8, 8), (3, 8)]:
+        m5, s5 = tuple(0.1 * (i + 1) for i in range(cin)), tuple(0.2 + 0.05 * i for i in range(cin))
+        u = r.integers(0, 256, (2, 4, 5, cin), dtype=np.uint8)
+        got = _cpu(H.preprocess_input(torch.from_numpy(u).to(H.DEV), cout, m5, s5))
+        ref = np.concatenate([_preprocess_ref(u, m5, s5), np.zeros((2, 4, 5, cout - cin), np.float32)], -1)
+        worst = max(worst, float(np.abs(got - ref).max()))
+    for cin, pad in [(3, (3, 3, 3, 3)), (3, (0, 1, 0, 1)), (1, (2, 0, 1, 4)), (4, (1, 1, 1, 1))]:
+        m4, s4 = (0.5, 0.4, 0.3, 0.2)[:cin], (0.25, 0.5, 0.2, 0.3)[:cin]
+        u = r.integers(0, 256, (2, 9, 6, cin), dtype=np.uint8)
+        got = _cpu(H.preprocess_input_pad(torch.from_numpy(u).to(H.DEV), pad, m4, s4))
+        ref = np.zeros((2, 9 + pad[0] + pad[1], 6 + pad[2] + pad[3], 4), np.float32)
+        ref[:, pad[0]:pad[0] + 9, pad[2]:pad[2] + 6, :cin] = _preprocess_ref(u, m4, s4)
+        worst = max(worst, float(np.abs(got - ref).max()))
+    H.sync()
+    return worst, 0.0
+
+
 def _dw_case(B, H, W, Cc, k, stride, padding, act, seed):
     import hip_ops as Hh
     r = _rng(seed)

@@ -147,6 +147,29 @@ def cast_input_pad(x, pad):
     return out
 
 
+def _norm_arrays(mean, std):
+    import ctypes as C
+    return (C.c_float * len(mean))(*[float(v) for v in mean]), (C.c_float * len(std))(*[float(v) for v in std])
+
+
+def preprocess_input(u8, c_out, mean, std):
+    B, H, W, Cin = u8.shape
+    out = torch.empty(B, H, W, c_out, dtype=torch.bfloat16, device=DEV)
+    m, s = _norm_arrays(mean, std)
+    ffi.check(lib.tfimm_hip_preprocess_input(ptr(u8), ptr(out), B * H * W, Cin, c_out, m, s, stream()), "preprocess_input")
+    return out
+
+
+def preprocess_input_pad(u8, pad, mean, std):
+    B, H, W, Cin = u8.shape
+    pt, pb, pl, pr = pad
+    out = torch.empty(B, H + pt + pb, W + pl + pr, 4, dtype=torch.bfloat16, device=DEV)
+    m, s = _norm_arrays(mean, std)
+    ffi.check(lib.tfimm_hip_preprocess_input_pad(ptr(u8), ptr(out), B, H, W, Cin, pt, pb, pl, pr, m, s, stream()),
+              "preprocess_input_pad")
+    return out
+
+
 def maxpool(x, k, stride, pad):
     B, H, W, Cc = x.shape
     OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1

@@ -113,3 +113,24 @@ def test_features_vit_mini():
     r = mc.compare_model("vit_test_model", batch=2, features=True)
     bad = {k: v for k, v in r.items() if k.startswith("feat:") and v > 2 * mc.TOL_LOGITS}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("name", ["resnet50_mini_test_model", "vit_hd64_test_model", "convnext_odd_test_model"])
+def test_deferred_uint8_preprocessing_matches_host_path(name):
+    """create_preprocessing(defer=True): uint8 pixels go to the device and (v/255 - mean)/std runs inside the
+    input-conversion kernel -- same logits, bit for bit, as preprocessing on the host in float32 (factory.py:165-167),
+    eagerly launched and replayed from the recorded graph."""
+    import tfimm
+    from tfimm.utils.init import synthetic_weights
+    m = tfimm.create_model(name)
+    m.set_weights(synthetic_weights(m))
+    H, W = m.cfg.input_size
+    img = np.random.default_rng(5).integers(0, 256, (3, H, W, m.cfg.in_channels), dtype=np.uint8)
+    host = m(tfimm.create_preprocessing(name)(img)).numpy()
+    pre = tfimm.create_preprocessing(name, defer=True)
+    eager = m(pre(img)).numpy()
+    replay = m(pre(img)).numpy()
+    img2 = 255 - img
+    replay2 = m(pre(img2)).numpy()
+    assert np.array_equal(host, eager) and np.array_equal(host, replay)
+    assert np.array_equal(replay2, m(tfimm.create_preprocessing(name)(img2)).numpy())

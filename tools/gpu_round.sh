@@ -16,6 +16,7 @@ for m in resnet50 vit_base_patch16_224 swin_base_patch4_window7_224 efficientnet
   timeout 300 python tools/op_profile.py $m > /dev/null 2> $O/opprof_$m.err; echo "opprof $m rc=$?"
   head -1 $O/opprof_$m.txt; grep "^##" $O/opprof_$m.txt | head -4
 done
+timeout 120 python tools/preprocess_probe.py > $O/preprocess_probe.txt 2>&1; tail -4 $O/preprocess_probe.txt
 export TFIMM_BENCH_EXTRA="vit_base_patch16_224,swin_base_patch4_window7_224,efficientnet_b4,convnext_tiny,cait_xxs24_224"
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 cut -c1-3000 $O/bench.json; tail -3 $O/bench.err
