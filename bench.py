@@ -98,7 +98,13 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
     gathered = torch.empty(world * batch, out_t.C, dtype=torch.float32, device="cuda") if world > 1 else None
 
     use_graph = graph and mb == batch
-    captured = plans[batch].capture(x) if use_graph else None
+    captured = None
+    if use_graph:
+        try:
+            captured = plans[batch].capture(x)
+        except RuntimeError as e:      # same launches one by one instead of one hipGraphLaunch; reported in config.graph
+            print(f"warning: hipGraph recording failed ({e}); launching eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
 
     def step(events=None):
         if captured is not None and events is None:

@@ -910,7 +910,9 @@ class CapturedPlan:
         plan.run(x_dev, norm=norm)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: only this thread's calls are recorded / policed -- a communicator's watchdog thread polling its
+        # events (one process per GPU, RCCL initialised before the recording) must not invalidate the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             plan.run(x_dev, norm=norm)       # (mean/std travel by value in the recorded launch)
 
     def replay(self):
