@@ -173,13 +173,14 @@ def run_with_events(plan, x_dev, events):
     from tfimm.engine.graph import _hip_memset_async
     B = plan.batch
     gi = 0
-    gemm_ops = plan.__dict__.setdefault("_gemm_ops", [op for op in plan.prog.ops if op.kind == "gemm"])
+    stem_fn = ffi.lib.tfimm_hip_stem_conv_pool       # the stem convolution (fused with its pooling): same family
+    gemm_ops = plan.__dict__.setdefault("_gemm_ops", [op for op in plan.prog.ops if op.kind in ("gemm", "stem_pool")])
     for i, (fn, args) in enumerate(plan.calls):
         if i == idx:
             rc = fn(x_dev.data_ptr(), in_dtype, *plan._input_call[1], st)
         elif fn == "memset":
             rc = _hip_memset_async(args[0], args[1], stream_ptr)
-        elif fn is gemm_fn:
+        elif fn is gemm_fn or fn is stem_fn:
             a = gemm_ops[gi].attrs
             gi += 1
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

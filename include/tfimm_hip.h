@@ -135,6 +135,25 @@ TFIMM_API int tfimm_hip_cast_input_pad(const void* in, int in_dtype, void* out, 
                              int pad_t, int pad_b, int pad_l, int pad_r, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * tfimm_hip_stem_conv_pool: the ResNet stem in one kernel -- ZeroPadding2D(3) + Conv2D 7x7 stride 2 (BN folded into
+ * weights and bias) + ReLU + ZeroPadding2D(1) + MaxPool2D 3x3 stride 2 (resnet.py:505-512, 538-540; forward_features
+ * :572-576).  x: the zero-bordered 4-channel image tfimm_hip_cast_input_pad / tfimm_hip_preprocess_input_pad wrote,
+ * viewed as pixel pairs [batch][Hp][Wp2][8] bf16 (Wp2 = padded width / 2 <= 116, Hp >= 2 (OH - 1) + 7).
+ * wt: [64][ldw] bf16 with k = ky * 32 + (kx / 2) * 8 + (kx % 2) * 4 + c (kx = 7 and c = 3 are zero), the layout of the
+ * unfused TFIMM_A_CONV call on the pair view; bias: 64 floats.  OH x OW (OW <= 112): size of the convolution output,
+ * which exists only in LDS; out: [batch][PH][PW][64] bf16, PH = (OH - 1) / 2 + 1, PW = (OW - 1) / 2 + 1.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x;
+  const void* wt;
+  const float* bias;
+  void* out;
+  int32_t batch, Hp, Wp2, OH, OW, ldw;
+} tfimm_stem_desc;
+
+TFIMM_API int tfimm_hip_stem_conv_pool(const tfimm_stem_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * tfimm_hip_preprocess_input / _pad: the two conversions above for a uint8 image with values in [0, 255], with the
  * model's preprocessing applied on the way: out = bf16(((float)v / 255 - mean[c]) / std[c]) -- the three float32
  * operations of create_preprocessing (models/factory.py:165-167; mean/std: utils/constants.py:3-6, tiled to c_in by

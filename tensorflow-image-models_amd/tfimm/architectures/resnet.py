@@ -200,12 +200,16 @@ class ResNet(Model):
             x = b.conv(x, "conv1/0/kernel", stride=2, padding=1, bn="conv1/1", bn_eps=eps, act=act, cite="resnet.py:473-481")
             x = b.conv(x, "conv1/3/kernel", padding="same", bn="conv1/4", bn_eps=eps, act=act, cite="resnet.py:482-490")
             x = b.conv(x, "conv1/6/kernel", padding="same", bn="bn1", bn_eps=eps, act=act, cite="resnet.py:491-500,513-514")
+            fused_pool = False
         else:
-            x = b.conv(x, "conv1/kernel", stride=2, padding=3, bn="bn1", bn_eps=eps, act=act, cite="resnet.py:505-514")
+            # plain stem: convolution and the pooling behind it go to the builder together (one kernel when it can)
+            fused_pool = not c.replace_stem_pool
+            x = b.conv(x, "conv1/kernel", stride=2, padding=3, bn="bn1", bn_eps=eps, act=act,
+                       then_maxpool=(3, 2, 1) if fused_pool else None, cite="resnet.py:505-514,538-540")
         # ---- stem pooling (resnet.py:517-540)
         if c.replace_stem_pool:
             x = b.conv(x, "maxpool/0/kernel", stride=2, padding=1, bn="maxpool/1", bn_eps=eps, act=act, cite="resnet.py:520-530")
-        else:
+        elif not fused_pool:
             x = b.maxpool(x, 3, 2, 1, cite="resnet.py:538-540")
         if want_features:
             b.p.mark_output("stem", x)

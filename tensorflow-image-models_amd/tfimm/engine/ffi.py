@@ -58,6 +58,14 @@ class ThaDesc(C.Structure):
     ]
 
 
+class StemDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("wt", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
+        ("batch", C.c_int32), ("Hp", C.c_int32), ("Wp2", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32),
+        ("ldw", C.c_int32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol declared in include/tfimm_hip.h
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SYMBOLS = {
@@ -65,6 +73,7 @@ SYMBOLS = {
     "tfimm_hip_last_error": (C.c_char_p, []),
     "tfimm_hip_device_info": (_i, [_i, C.c_char_p, _i]),
     "tfimm_hip_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
+    "tfimm_hip_stem_conv_pool": (_i, [C.POINTER(StemDesc), _vp]),
     "tfimm_hip_cast_input": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp]),
     "tfimm_hip_cast_input_pad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tfimm_hip_preprocess_input": (_i, [_vp, _vp, _i64, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),

@@ -11,6 +11,7 @@ Activations are bf16 ``[B * rows_per_image, C]`` row-major (NHWC flattened); a t
 carry its spatial extent ``(H, W)``.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -101,7 +102,7 @@ class Program:
         total = 0
         for op in self.ops:
             a = op.attrs
-            if op.kind == "gemm":
+            if op.kind in ("gemm", "stem_pool"):
                 total += 2 * a["M"] * a["N"] * a["K_true"]
             elif op.kind in ("attention", "talking_heads_attention"):
                 total += a["flops"]
@@ -219,11 +220,15 @@ class Builder:
     def conv(self, x: TRef, kernel: str, *, stride=1, padding=0, bn: Optional[str] = None,
              bn_eps=1e-5, bias: Optional[str] = None, act="", residual: Optional[TRef] = None,
              act_after_res=False, a_scale: Optional[TRef] = None, flatten=False,
-             remap=None, res_const=None, res_mod=0, cite="", name="") -> TRef:
+             remap=None, res_const=None, res_mod=0, then_maxpool=None, cite="", name="") -> TRef:
         """Conv2D (+ZeroPadding2D / "same") + folded BN / bias + activation + residual.
 
         ``padding``: int (symmetric, as the reference's ZeroPadding2D + VALID), "same"
         (TF asymmetric, layers/conv.py:61) or an explicit ``((top, bottom), (left, right))``.
+        ``then_maxpool=(k, stride, pad)``: the max pooling that follows (resnet.py:538-540).  The ResNet stem shape
+        (7x7 stride 2 on the RGB image, 64 channels, ReLU, 3x3 / 2 / 1 pooling, at most 112 output columns) runs as ONE
+        kernel that never writes the convolution output (tfimm_hip_stem_conv_pool); anything else is the convolution
+        followed by ``maxpool``.
         """
         p = self.p
         k = self.wget(kernel)
@@ -272,6 +277,15 @@ class Builder:
             xt = p.tensors[x.id]
             xt.rows, xt.H, xt.W = hp * wp, hp, wp
             wt, bvec, kk, _ = pack.pack_conv(k, scale, shift, 4)   # K order (ky, kx < kwp, c < 4) == (ky, pair, 8)
+            if (then_maxpool == (3, 2, 1) and kh == 7 and kw == 7 and stride == 2 and cout == 64 and act == "relu"
+                    and OW <= 112 and wp // 2 <= 116 and residual is None and remap is None and not flatten
+                    and bvec is not None and os.environ.get("TFIMM_NO_STEM_FUSION", "0") != "1"):
+                PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
+                pooled = p.new_tensor(PH * PW, cout, PH, PW, name=name or kernel)
+                consts = {"wt": p.new_const(wt, kernel), "bias": p.new_const(bvec, kernel + ":bias")}
+                p.add("stem_pool", [x], pooled, consts, cite=cite, Hp=hp, Wp2=wp // 2, OH=OH, OW=OW, ldw=wt.shape[1],
+                      N=cout, K_true=kh * kw * cin, M=M)
+                return pooled
             attrs.update(mode=1, K=kk, H=hp, W=wp // 2, Cin=8, KH=kh, KW=kwp // 2, stride=stride, stride_w=stride // 2,
                          pad_t=0, pad_l=0, OH=OH, OW=OW)
         elif pointwise:
@@ -302,6 +316,8 @@ class Builder:
             # rows land in a larger token buffer: (rows_in_per_image, rows_out_per_image, offset)
             out.rows = remap[1]
         p.add("gemm", ins, out, consts, cite=cite, **attrs)
+        if then_maxpool is not None:
+            return self.maxpool(out, *then_maxpool, cite=cite)
         return out
 
     def dense(self, x: TRef, kernel: str, bias: Optional[str] = None, *, act="",
@@ -701,6 +717,13 @@ class Plan:
                 self.calls.append((lib.tfimm_hip_copy_rows,
                                    (self.tptr(op.inputs[0]), self.tptr(op.output), B, a["src_rows"], a["dst_rows"],
                                     a["dst_row0"], a["d"])))
+            elif k == "stem_pool":
+                d = ffi.StemDesc()
+                d.x, d.out = self.tptr(op.inputs[0]), self.tptr(op.output)
+                d.wt, d.bias = self.cptr(op.consts["wt"]), self.cptr(op.consts["bias"])
+                d.batch, d.Hp, d.Wp2, d.OH, d.OW, d.ldw = B, a["Hp"], a["Wp2"], a["OH"], a["OW"], a["ldw"]
+                self._keepalive.append(d)
+                self.calls.append((lib.tfimm_hip_stem_conv_pool, (C.byref(d),)))
             elif k == "maxpool":
                 self.calls.append((lib.tfimm_hip_maxpool,
                                    (self.tptr(op.inputs[0]), self.tptr(op.output), B, a["H"], a["W"], a["C"],

@@ -242,6 +242,37 @@ for _t in (1, 2, 3, 4, 5, 6, 11, 12, 13, 14, 15, 16, 21, 22, 23, 24, 25, 26, 27,
         lambda t=_t: _conv_case(3, 15, 13, 40, 72, 3, 2, 1, act="relu", residual=True, seed=43, tile=t))
 
 
+def _stem_pool_case(B, H, W, seed, cin=3):
+    """fused ResNet stem (tfimm_hip_stem_conv_pool) against conv 7x7/2 pad 3 + BN + ReLU + zero-pad 1 + maxpool 3x3/2 of
+    the oracle; the convolution output is rounded to bf16 before the pooling, as the unfused engine path stores it"""
+    import hip_ops as Hh
+    r = _rng(seed)
+    k, stride, Cout = 7, 2, 64
+    x = _bf(r.standard_normal((B, H, W, cin)))
+    kern = (r.standard_normal((k, k, cin, Cout)) / math.sqrt(k * k * cin)).astype(np.float32)
+    scale = r.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = r.standard_normal(Cout).astype(np.float32)
+    wt, bias, K, _ = pack.pack_conv(kern, scale, shift, 4)
+    kf = _bf(kern * scale.reshape(1, 1, 1, -1))
+    y = O.conv2d(O.zero_pad2d(torch.from_numpy(x), 3), torch.from_numpy(kf), None, stride=stride) + torch.from_numpy(shift)
+    y = torch.from_numpy(_bf(O.activation(y, "relu").numpy()))
+    OH, OW = y.shape[1], y.shape[2]
+    ref = O.max_pool2d(O.zero_pad2d(y, 1), 3, 2).numpy()
+    wp = max(W + 3, (OW - 1) * stride + 8)
+    wp += wp & 1
+    hp = max(H + 3, (OH - 1) * stride + k)
+    xp = Hh.cast_input_pad(Hh.dev_bf16(x), (3, hp - H - 3, 3, wp - W - 3))
+    got = Hh.stem_conv_pool(xp, Hh.dev_bits(wt), Hh.dev_f32(bias), B, hp, wp // 2, OH, OW)
+    Hh.sync()
+    return _err(_cpu(got), ref), TOL_BF16
+
+
+CASES["stem_pool_224_b3"] = lambda: _stem_pool_case(3, 224, 224, 150)            # bands > 1 (few images)
+CASES["stem_pool_160x128"] = lambda: _stem_pool_case(2, 160, 128, 151)
+CASES["stem_pool_odd_70x54"] = lambda: _stem_pool_case(2, 70, 54, 152)           # OH = 35 (ragged last step), OW = 27
+CASES["stem_pool_tiny_9x11"] = lambda: _stem_pool_case(1, 9, 11, 153)
+CASES["stem_pool_many_images"] = lambda: _stem_pool_case(300, 32, 32, 154)       # more items than workgroups
+CASES["stem_pool_gray"] = lambda: _stem_pool_case(2, 64, 48, 155, cin=1)
 CASES["pair_conv7x7_s2_p3_rgb_stem"] = lambda: _conv_case(2, 64, 64, 3, 64, 7, 2, 3, act="relu", seed=134, pair=True)
 CASES["pair_conv7x7_s2_p3_rgb_stem_big"] = lambda: _conv_case(3, 224, 224, 3, 64, 7, 2, 3, act="relu", seed=139, pair=True)
 CASES["pair_conv16x16_s16_rgb_patch"] = lambda: _conv_case(2, 64, 64, 3, 96, 16, 16, 0, bn=False, seed=135, pair=True)

@@ -34,6 +34,11 @@ def op_bytes_flops(op, prog, B):
         return byts, 2.0 * M * N * K, f"M={M} K={a['K']} N={N} mode={a['mode']}" + \
             (f" {a['KH']}x{a['KW']}s{a['stride']} {a['H']}->{a['OH']}" if a["mode"] else "") + \
             (" +res" if a.get("has_residual") else "") + (f" {a['act']}" if a["act"] else "")
+    if k == "stem_pool":
+        M = a["M"] * B
+        pooled = ((a["OH"] - 1) // 2 + 1) * ((a["OW"] - 1) // 2 + 1)
+        byts = B * a["Hp"] * a["Wp2"] * 16 + a["N"] * a["ldw"] * 2 + B * pooled * a["N"] * 2
+        return byts, 2.0 * M * a["N"] * a["K_true"], f"M={M} 7x7s2 {a['OH']}x{a['OW']} -> relu -> maxpool3x3s2 (fused)"
     if k == "talking_heads_attention":
         rows = B * a["n_tokens"]
         d = a["heads"] * a["hd"]

@@ -34,6 +34,28 @@ __global__ void __launch_bounds__(512) k(float* out, int iters, long long* clk, 
   if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
 }
 
+// the same for v_mfma_f32_16x16x32_bf16 (modes 10 / 11 / 12: 8 / 2 / 4 accumulators)
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <int NACC>
+__global__ void __launch_bounds__(512) k16(float* out, int iters, long long* clk, int rnd) {
+  f32x4 acc[NACC];
+  for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 a, b;
+  for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(float)(threadIdx.x & 3); b[e] = (__bf16)1.0f; }
+  long long t0 = clock64(), w0 = wall_clock64();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int r = 0; r < 8 / NACC; ++r)
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+  }
+  long long t1 = clock64(), w1 = wall_clock64();
+  float s = 0.f;
+  for (int i = 0; i < NACC; ++i) s += acc[i][0];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
+}
+
 int main(int argc, char** argv) {
   int mode = argc > 1 ? atoi(argv[1]) : 0;
   int blocks = argc > 2 ? atoi(argv[2]) : 256;
@@ -45,11 +67,13 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(e0);
+    if (mode == 10) k16<8><<<blocks, threads>>>(out, iters, clk, rnd); else if (mode == 11) k16<2><<<blocks, threads>>>(out, iters, clk, rnd);
+    else if (mode == 12) k16<4><<<blocks, threads>>>(out, iters, clk, rnd); else
     if (mode == 0) k<8><<<blocks, threads>>>(out, iters, clk, rnd); else if (mode == 1) k<2><<<blocks, threads>>>(out, iters, clk, rnd); else k<4><<<blocks, threads>>>(out, iters, clk, rnd);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     long long h[2]; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
-    double flops = (double)blocks * (threads / 64) * iters * 8 * 32768.0;
+    double flops = (double)blocks * (threads / 64) * iters * 8 * (mode >= 10 ? 16384.0 : 32768.0);
     printf("mode %d blocks %d: %.2f ms %.1f TF/s; clock64 %lld wall %lld -> shader clock %.0f MHz (if wall=100MHz); cycles/MFMA/wave %.1f\n",
            mode, blocks, ms, flops / ms / 1e9, h[0], h[1], 100.0 * h[0] / h[1], (double)h[0] / (iters * 8.0));
   }
