@@ -287,7 +287,7 @@ def main():
                         frac=round(achieved / peak, 4), traffic=traffic, traffic_unit="HBM bytes per launch (PMC)",
                         traffic_source=traffic_src, algorithmic_bytes_per_launch=(
                             None if bound == "mfma" else round(alg / launches_per_step)),
-                        kernel="tfimm_gemm::gemm_kernel (all flavours)",
+                        kernel="tfimm_gemm::* (all GEMM / convolution flavours) + stem_pool_kernel",
                         launches_per_step=launches_per_step, avg_launch_ms=round(avg_ms, 5),
                         share_of_step=round(gk["ms"] / args.steps / ms, 3),
                         timing="HIP event pair around every launch, on the launch stream, over K eagerly launched "
