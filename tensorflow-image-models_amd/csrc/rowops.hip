@@ -305,6 +305,70 @@ __global__ void __launch_bounds__(256) layernorm_narrow_kernel(const bf16_t* __r
   }
 }
 
+// d = 3 * LPR * 8 exactly (384, 768: DeiT-S / CaiT-S / ConvNeXt / ViT-B widths): LPR lanes per row with three
+// 16-byte chunks each (c, c + LPR, c + 2 LPR), so every lane of the wave is busy -- the one-wave-per-row kernel would
+// leave a third of its second chunk slots (d = 768) or whole lanes (d = 384) idle
+template <int LPR>
+__global__ void __launch_bounds__(256) layernorm_x3_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int64_t rows,
+                                                           int64_t xs, int64_t ys, float eps) {
+  constexpr int RPW = 64 / LPR;
+  constexpr float inv_d = 1.f / (float)(24 * LPR);
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / LPR, c = lane % LPR;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  float gg[3][8], bb[3][8];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int ch = c + i * LPR;
+    const float4 g0 = reinterpret_cast<const float4*>(gamma)[2 * ch], g1 = reinterpret_cast<const float4*>(gamma)[2 * ch + 1];
+    const float4 b0 = reinterpret_cast<const float4*>(beta)[2 * ch], b1 = reinterpret_cast<const float4*>(beta)[2 * ch + 1];
+    gg[i][0] = g0.x; gg[i][1] = g0.y; gg[i][2] = g0.z; gg[i][3] = g0.w; gg[i][4] = g1.x; gg[i][5] = g1.y; gg[i][6] = g1.z; gg[i][7] = g1.w;
+    bb[i][0] = b0.x; bb[i][1] = b0.y; bb[i][2] = b0.z; bb[i][3] = b0.w; bb[i][4] = b1.x; bb[i][5] = b1.y; bb[i][6] = b1.z; bb[i][7] = b1.w;
+  }
+  auto group_sum = [&](float v) -> float {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  for (int64_t r0 = wave0 * RPW; r0 < rows; r0 += nwaves * RPW) {
+    const int64_t r = r0 + sub;
+    const bool ok = r < rows;
+    float v[3][8];
+    uint4 u[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) u[i] = ok ? reinterpret_cast<const uint4*>(x + r * xs)[c + i * LPR] : make_uint4(0u, 0u, 0u, 0u);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      unpack8(u[i], v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += v[i][e];
+    }
+    const float mean = group_sum(sum) * inv_d;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float t = v[i][e] - mean;
+        sq += t * t;
+      }
+    const float rstd = rsqrtf(group_sum(sq) * inv_d + eps);
+    if (ok) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * gg[i][e] + bb[i][e];
+        reinterpret_cast<uint4*>(y + r * ys)[c + i * LPR] = pack8(o);
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) layernorm_generic_kernel(const bf16_t* x, bf16_t* y, const float* gamma,
                                                                 const float* beta, int64_t rows, int d,
                                                                 int64_t xs, int64_t ys, float eps) {
@@ -1098,6 +1162,16 @@ extern "C" int tfimm_hip_layernorm(const void* x, void* y, const float* gamma, c
   const bf16_t* xb = (const bf16_t*)x;
   bf16_t* yb = (bf16_t*)y;
   if (vec) {
+    static const bool no_x3 = getenv("TFIMM_LN_NO_X3") != nullptr;      // (A/B switch for profiling)
+    // (measured, MI355X: d = 768 71.6 -> 51.9 us for 100864 rows, d = 384 17.1 -> 15.2 us for 50176 rows; d = 192 / 96
+    //  are no faster than the narrow kernel below -- 64-byte row pieces per lane group -- and stay there)
+    if (!no_x3 && (d == 384 || d == 768)) {
+      const int lpr = d / 24, rpw = 64 / lpr;
+      const unsigned gr = grid_for((rows + rpw - 1) / rpw, 4);
+      if (lpr == 16) TFIMM_LAUNCH(layernorm_x3_kernel<16>, dim3(gr), dim3(256), 0, st, xb, yb, gamma, beta, rows, x_stride, y_stride, eps);
+      else TFIMM_LAUNCH(layernorm_x3_kernel<32>, dim3(gr), dim3(256), 0, st, xb, yb, gamma, beta, rows, x_stride, y_stride, eps);
+      return 0;
+    }
     if (d <= 64) {
       const unsigned g8 = grid_for((rows + 7) / 8, 4);
       TFIMM_LAUNCH(layernorm_narrow_kernel<8>, dim3(g8), dim3(256), 0, st, xb, yb, gamma, beta, rows, d, x_stride, y_stride, eps);

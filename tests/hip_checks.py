@@ -321,6 +321,7 @@ def _ln_case(rows, d, eps, seed):
 
 CASES["layernorm_768"] = lambda: _ln_case(197 * 3, 768, 1e-6, 50)
 CASES["layernorm_192"] = lambda: _ln_case(50, 192, 1e-6, 51)
+CASES["layernorm_384_rows_tail"] = lambda: _ln_case(1001, 384, 1e-6, 62)            # 16 lanes x 3 chunks, 4 rows per wave
 CASES["layernorm_1024"] = lambda: _ln_case(33, 1024, 1e-5, 52)
 CASES["layernorm_2048"] = lambda: _ln_case(9, 2048, 1e-5, 53)
 CASES["layernorm_4096"] = lambda: _ln_case(5, 4096, 1e-5, 54)
