@@ -34,6 +34,7 @@ struct AttnArgs {
   int vec;      // hd % 8 == 0 and all rows 16-byte aligned
   int ld;       // 3 * heads * hd
   int dmodel;   // heads * hd
+  int dbg;      // TFIMM_ATTN_DBG (profiling only): 1 skip the key loop, 2 skip K/V staging
 };
 
 template <bool SWIN>
@@ -346,7 +347,7 @@ __global__ void __launch_bounds__(NW * 64) attn_resident_kernel(const AttnArgs p
   }
 
   // ---- stage K (16-byte stores)
-  for (int id = tid; id < nkp * CH; id += NT) {
+  for (int id = (p.dbg & 2) ? nkp * CH : tid; id < nkp * CH; id += NT) {
     const int key = id / CH, c = id - key * CH;
     uint4 ku = make_uint4(0u, 0u, 0u, 0u);
     if (key < p.n && c * 8 < p.hd) {
@@ -367,7 +368,7 @@ __global__ void __launch_bounds__(NW * 64) attn_resident_kernel(const AttnArgs p
     Ks[k_slot<HD>(key, c)] = ku;
   }
   // ---- stage V row-major (16-byte stores, same coalescing as K)
-  for (int id = tid; id < nkp * CH; id += NT) {
+  for (int id = (p.dbg & 2) ? nkp * CH : tid; id < nkp * CH; id += NT) {
     const int key = id / CH, c = id - key * CH;
     uint4 vu = make_uint4(0u, 0u, 0u, 0u);
     if (key < p.n && c * 8 < p.hd) {
@@ -423,7 +424,7 @@ __global__ void __launch_bounds__(NW * 64) attn_resident_kernel(const AttnArgs p
   const bool two = TQ == 2 && (wave + NW) * 16 < p.n;   // second tile present (wave-uniform)
 
   if (wave * 16 < p.n) {
-    for (int kb = 0; kb < nkb; ++kb) {
+    for (int kb = (p.dbg & 1) ? nkb : 0; kb < nkb; ++kb) {
       // ---- raw scores S^T[key][q] of the 4 key tiles of this block, both query tiles
       f32x4 acc[TQ][4];
 #pragma unroll
@@ -545,6 +546,240 @@ __global__ void __launch_bounds__(NW * 64) attn_resident_kernel(const AttnArgs p
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Global attention (ViT / DeiT / CaiT main blocks), persistent: one workgroup per CU walks a list of
+// (image, head) items.  While item i is being computed from LDS, the K and V rows and the Q fragments of
+// item i + 1 are already on their way from HBM into registers (8 + 8 x 16 bytes per thread at n <= 256);
+// they are written to LDS when item i is done.  Measured on ViT-B/16 (batch 512): the one-item-per-workgroup
+// kernel above spends 91 us in Q loads / O stores / launches, +59 us in K/V staging, +82 us in arithmetic,
+// strictly one after the other (232 us; the HBM floor is ~120 us).  This kernel: 16 waves x one query tile (8 x 2
+// leaves two waves per SIMD and is slower), 215 us -- the arithmetic (VALU-bound on the exponentials of the padded
+// 256 x 256 score block) now hides the loads, and is what is left.
+// Same arithmetic as attn_resident_kernel (vec layout only: hd == HD, 16-byte aligned rows).
+// ---------------------------------------------------------------------------------------------
+// K / V pieces and Q fragments of one (image, head) item, held in registers while the previous item is computed.
+// Named members, not arrays: hipcc left the array version of this in scratch memory (store after every load = a
+// wait for it), which serialised exactly what is meant to overlap.
+typedef __attribute__((ext_vector_type(4))) unsigned int attn_u32x4;    // (a vector, not HIP's uint4 struct)
+struct AttnPrefetch {
+  attn_u32x4 k0, k1, k2, k3, v0, v1, v2, v3;
+  attn_u32x4 q00, q01, q10, q11;     // [query tile][k-step]
+};
+
+// Unconditional loads from clamped rows: a select on a loaded value would make hipcc wait for it during the arithmetic.
+template <int HD, int PF, int KS, int NT, int TQ>
+__device__ __forceinline__ void attn_fetch_item(const AttnArgs& p, int item, int tid, int q0, int q1, int g, AttnPrefetch& r) {
+  constexpr int CH = HD / 8;
+  const int h = item % p.heads, seq = item / p.heads;
+  const bf16_t* base = p.qkv + (int64_t)seq * p.n_tokens * p.ld + h * HD;
+  auto piece = [&](int j, attn_u32x4& k, attn_u32x4& v) __attribute__((always_inline)) {
+    const int id = tid + j * NT;
+    const int key = id / CH, c = id - key * CH;
+    const bf16_t* kp = base + (int64_t)min(key, p.n - 1) * p.ld + p.dmodel + c * 8;
+    k = *reinterpret_cast<const attn_u32x4*>(kp);
+    v = *reinterpret_cast<const attn_u32x4*>(kp + p.dmodel);
+  };
+  piece(0, r.k0, r.v0);
+  if (PF > 1) piece(1, r.k1, r.v1);
+  if (PF > 2) piece(2, r.k2, r.v2);
+  if (PF > 3) piece(3, r.k3, r.v3);
+  const bf16_t* qa = base + (int64_t)min(q0, p.n - 1) * p.ld + g * 8;
+  r.q00 = *reinterpret_cast<const attn_u32x4*>(qa);
+  if (KS > 1) r.q01 = *reinterpret_cast<const attn_u32x4*>(qa + 32);
+  if (TQ > 1) {
+    const bf16_t* qb = base + (int64_t)min(q1, p.n - 1) * p.ld + g * 8;
+    r.q10 = *reinterpret_cast<const attn_u32x4*>(qb);
+    if (KS > 1) r.q11 = *reinterpret_cast<const attn_u32x4*>(qb + 32);
+  }
+}
+
+template <int HD, int NW, int TQ>
+__global__ void __launch_bounds__(NW * 64) attn_stream_kernel(const AttnArgs p, const int nkp, const int items) {
+  constexpr int NT = NW * 64;
+  static_assert(NW * TQ == 16, "16 query tiles: n <= 256");
+  constexpr int CH = HD / 8;
+  constexpr int KROW = HD == 64 ? 8 : CH + 1;
+  constexpr int KS = HD / 32;
+  constexpr int DT = HD / 16;
+  constexpr int PF = 256 * CH / NT;          // 16-byte K (and V) pieces per thread for nkp = 256
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) char smem_attn[];
+  uint4* Ks = reinterpret_cast<uint4*>(smem_attn);
+  uint4* Vs = Ks + (size_t)nkp * KROW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const float cs = p.scale * LOG2E;
+  const int nkb = (p.n + 63) >> 6;
+  const bool two = TQ == 2 && (wave + NW) * 16 < p.n;   // second query tile present (wave-uniform)
+  const bool active = wave * 16 < p.n;
+
+  int qi[TQ];
+  bool q_ok[TQ];
+#pragma unroll
+  for (int u = 0; u < TQ; ++u) {
+    qi[u] = (wave + u * NW) * 16 + l15;
+    q_ok[u] = qi[u] < p.n;
+  }
+  AttnPrefetch pre;
+  int item = blockIdx.x;
+  if (item < items) attn_fetch_item<HD, PF, KS, NT, TQ>(p, item, tid, qi[0], qi[TQ - 1], g, pre);
+  for (; item < items; item += gridDim.x) {
+    __syncthreads();                          // every wave is done reading the previous item's K / V
+    // rows n .. nkp-1 hold copies of row n-1: their scores are masked to -inf below and their P is 0
+    auto put = [&](int j, const attn_u32x4 k, const attn_u32x4 v) __attribute__((always_inline)) {
+      const int id = tid + j * NT;
+      const int key = id / CH, c = id - key * CH;
+      if (key < nkp) {
+        reinterpret_cast<attn_u32x4*>(Ks)[k_slot<HD>(key, c)] = k;
+        reinterpret_cast<attn_u32x4*>(Vs)[v_slot<HD>(key, c)] = v;
+      }
+    };
+    put(0, pre.k0, pre.v0);
+    if (PF > 1) put(1, pre.k1, pre.v1);
+    if (PF > 2) put(2, pre.k2, pre.v2);
+    if (PF > 3) put(3, pre.k3, pre.v3);
+    bf16x8 qf[TQ][KS];             // (queries beyond n: a copy of query n-1, never stored)
+    qf[0][0] = __builtin_bit_cast(bf16x8, pre.q00);
+    if (KS > 1) qf[0][KS - 1] = __builtin_bit_cast(bf16x8, pre.q01);
+    if (TQ > 1) {
+      qf[TQ - 1][0] = __builtin_bit_cast(bf16x8, pre.q10);
+      if (KS > 1) qf[TQ - 1][KS - 1] = __builtin_bit_cast(bf16x8, pre.q11);
+    }
+    __syncthreads();
+    if (item + (int)gridDim.x < items && !(p.dbg & 2))          // in flight during the arithmetic below
+      attn_fetch_item<HD, PF, KS, NT, TQ>(p, item + gridDim.x, tid, qi[0], qi[TQ - 1], g, pre);
+
+    const int h = item % p.heads, seq = item / p.heads;
+    f32x4 o[TQ][DT];
+    float m_run[TQ], l_run[TQ];
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+#pragma unroll
+      for (int i = 0; i < DT; ++i) o[u][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      m_run[u] = -1e30f;
+      l_run[u] = 0.f;
+    }
+    if (active) {
+      for (int kb = (p.dbg & 1) ? nkb : 0; kb < nkb; ++kb) {
+        f32x4 acc[TQ][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+          for (int u = 0; u < TQ; ++u) acc[u][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 kf = __builtin_bit_cast(bf16x8, Ks[k_slot<HD>(kb * 64 + t * 16 + l15, ks * 4 + g)]);
+#pragma unroll
+            for (int u = 0; u < TQ; ++u)
+              if (u == 0 || two) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], acc[u][t], 0, 0, 0);
+          }
+        }
+        bf16x8 pf[TQ][2];
+#pragma unroll
+        for (int u = 0; u < TQ; ++u) {
+          if (u == 1 && !two) break;
+          float sc[16];
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[t * 4 + r] = acc[u][t][r];
+          if (kb * 64 + 64 > p.n) {   // last block: keys beyond n never win the max and get p = 0
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (kb * 64 + t * 16 + g * 4 + r >= p.n) sc[t * 4 + r] = -__builtin_inff();
+          }
+          // online softmax, exp2 domain: sc are RAW scores, the scale rides on the FMA
+          float mloc = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+#pragma unroll
+          for (int i = 3; i < 15; i += 2) mloc = fmaxf(fmaxf(mloc, sc[i]), sc[i + 1]);
+          mloc = fmaxf(mloc, sc[15]);
+          mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+          mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+          const float m_new = fmaxf(m_run[u], mloc * cs);
+          const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);
+          float psum = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            sc[i] = __builtin_amdgcn_exp2f(fmaf(sc[i], cs, -m_new));
+            psum += sc[i];
+          }
+          l_run[u] = l_run[u] * alpha + psum;
+          m_run[u] = m_new;
+#pragma unroll
+          for (int i = 0; i < DT; ++i) o[u][i] *= alpha;
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            uint4 pu;
+            pu.x = pack_bf2(sc[8 * s2 + 0], sc[8 * s2 + 1]);
+            pu.y = pack_bf2(sc[8 * s2 + 2], sc[8 * s2 + 3]);
+            pu.z = pack_bf2(sc[8 * s2 + 4], sc[8 * s2 + 5]);
+            pu.w = pack_bf2(sc[8 * s2 + 6], sc[8 * s2 + 7]);
+            pf[u][s2] = __builtin_bit_cast(bf16x8, pu);
+          }
+        }
+        typedef __attribute__((ext_vector_type(4))) short s16x4;
+        typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const int krow = kb * 64 + g * 4 + (l15 >> 2);
+            const int chunk = dt * 2 + ((l15 & 3) >> 1);
+            const char* base = reinterpret_cast<const char*>(Vs) + (l15 & 1) * 8;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (lds_s16x4_ptr)(base + (size_t)v_slot<HD>(krow + (2 * s2) * 16, chunk) * 16));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (lds_s16x4_ptr)(base + (size_t)v_slot<HD>(krow + (2 * s2 + 1) * 16, chunk) * 16));
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            const s16x8 cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8 vf = __builtin_bit_cast(bf16x8, cat);
+#pragma unroll
+            for (int u = 0; u < TQ; ++u)
+              if (u == 0 || two) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u][s2], o[u][dt], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < TQ; ++u) {
+        float l_tot = l_run[u] + __shfl_xor(l_run[u], 16, 64);
+        l_tot += __shfl_xor(l_tot, 32, 64);
+        if (q_ok[u]) {
+          const float inv = 1.f / l_tot;
+          bf16_t* op = p.out + ((int64_t)seq * p.n_tokens + qi[u]) * p.dmodel + h * HD;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const int d0 = dt * 16 + g * 4;
+            *reinterpret_cast<uint2*>(op + d0) = make_uint2(pack_bf2(o[u][dt][0] * inv, o[u][dt][1] * inv),
+                                                            pack_bf2(o[u][dt][2] * inv, o[u][dt][3] * inv));
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int HD, int NW, int TQ>
+static int launch_attn_stream(const AttnArgs& a, int64_t nseq, hipStream_t st) {
+  const int nkp = (a.n + 63) / 64 * 64;
+  const int krow = HD == 64 ? 8 : HD / 8 + 1;
+  const size_t lds = (size_t)nkp * krow * 16 + (size_t)nkp * (HD / 8) * 16;
+  static bool attr_done = false;
+  static int cus = 256;
+  if (!attr_done) {
+    TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)attn_stream_kernel<HD, NW, TQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      cus = v;
+    attr_done = true;
+  }
+  const int64_t items = nseq * a.heads;
+  const int grid = (int)(items < cus ? items : cus);
+  TFIMM_LAUNCH((attn_stream_kernel<HD, NW, TQ>), dim3((unsigned)grid), dim3(NW * 64), lds, st, a, nkp, (int)items);
+  return 0;
+}
+
 template <int HD>
 static size_t attn_resident_lds(int n, bool swin, bool tiles) {
   const int nkp = (n + 63) / 64 * 64;
@@ -592,6 +827,8 @@ extern "C" int tfimm_hip_attention(const tfimm_attn_desc* dp, void* stream) {
   a.batch = d.batch; a.n_tokens = d.n_tokens; a.heads = d.heads; a.hd = d.hd; a.scale = d.scale;
   a.window = d.window; a.shift = d.shift; a.res_h = d.res_h; a.res_w = d.res_w;
   a.dmodel = d.heads * d.hd; a.ld = 3 * a.dmodel;
+  static const int attn_dbg = getenv("TFIMM_ATTN_DBG") ? atoi(getenv("TFIMM_ATTN_DBG")) : 0;
+  a.dbg = attn_dbg;
   int64_t nseq;
   if (d.window > 0) {
     if (d.res_h <= 0 || d.res_w <= 0 || d.res_h % d.window || d.res_w % d.window ||
@@ -620,6 +857,13 @@ extern "C" int tfimm_hip_attention(const tfimm_attn_desc* dp, void* stream) {
       const char* e = getenv("TFIMM_ATTN_NO_RESIDENT");
       use_resident = (e && e[0] == '1') ? 0 : 1;
     }
+    // global attention at head dim 64 with 9..16 query tiles (n = 129..256: ViT / DeiT / CaiT at 224) and enough items
+    // to keep every CU's workgroup busy for several rounds: the persistent kernel (measured 5-9 % faster on ViT-B;
+    // no gain at head dim 32 or with few heads, which stay on the kernel below)
+    static const bool no_stream = getenv("TFIMM_ATTN_NO_STREAM") != nullptr;
+    if (use_resident && !no_stream && d.window == 0 && a.vec && a.n > 128 && a.n <= 256 && d.hd == 64 &&
+        nseq * d.heads >= 2048 && nseq * d.heads <= 0x7fffffffLL)
+      return launch_attn_stream<64, 16, 1>(a, nseq, st);
     if (use_resident && lds <= 80 * 1024 && a.n <= 256 && nseq * d.heads <= 0x7fffffffLL) {
       if (d.window > 0)
         return d.hd <= 32 ? launch_attn_resident_any<32, true>(a, nseq, st) : launch_attn_resident_any<64, true>(a, nseq, st);

@@ -532,6 +532,13 @@ CASES["swin_tiles_w7_shift3_21x35"] = lambda: _swin_case(2, 21, 35, 3, 32, 7, 3,
 CASES["swin_tiles_w4_shift2_8x8_hd4"] = lambda: _swin_case(2, 8, 8, 1, 4, 4, 2, 80, tiles=True)
 CASES["swin_tiles_w12_shift6_24x24"] = lambda: _swin_case(1, 24, 24, 2, 32, 12, 6, 81, tiles=True)
 CASES["swin_tiles_w7_shift3_single_row"] = lambda: _swin_case(2, 7, 21, 2, 32, 7, 3, 82, tiles=True)
+# persistent global-attention kernel (>= 2048 (image, head) items, 129..256 tokens, head dim 64): several items per
+# workgroup, the last round ragged; 197 / 256 / 129 tokens
+CASES["attn_stream_197_hd64"] = lambda: _attn_case(171, 197, 12, 64, 160)
+CASES["attn_stream_197_spike"] = lambda: _attn_case(342, 197, 6, 64, 161, spike=True)
+CASES["attn_stream_256_hd64"] = lambda: _attn_case(129, 256, 16, 64, 162)
+CASES["attn_stream_129_hd64"] = lambda: _attn_case(257, 129, 8, 64, 163)
+CASES["attn_stream_200_hd32_stays_resident"] = lambda: _attn_case(64, 200, 17, 32, 164)
 CASES["attn_256_exact"] = lambda: _attn_case(1, 256, 2, 64, 68)
 CASES["attn_130_hd32"] = lambda: _attn_case(2, 130, 2, 32, 69)
 
