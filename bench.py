@@ -177,7 +177,7 @@ def run_with_events(plan, x_dev, events):
     gemm_ops = plan.__dict__.setdefault("_gemm_ops", [op for op in plan.prog.ops if op.kind in ("gemm", "stem_pool")])
     for i, (fn, args) in enumerate(plan.calls):
         if i == idx:
-            rc = fn(x_dev.data_ptr(), in_dtype, *plan._input_call[1], st)
+            rc = plan.launch_input(x_dev, st)
         elif fn == "memset":
             rc = _hip_memset_async(args[0], args[1], stream_ptr)
         elif fn is gemm_fn or fn is stem_fn:

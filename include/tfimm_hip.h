@@ -149,6 +149,11 @@ typedef struct {
   const float* bias;
   void* out;
   int32_t batch, Hp, Wp2, OH, OW, ldw;
+  /* in_dtype 0: x is the padded pair view described above.  1 / 2: x is the caller's own [batch][H][W][3] image in
+   * bf16 / float32 and the kernel applies the border (pad_t rows above, pad_l columns left, zeros to Hp x 2 Wp2), the
+   * zero 4th channel and the bf16 rounding of tfimm_hip_cast_input_pad itself -- that launch and its 8 bytes per
+   * pixel of HBM traffic disappear.  Hp, Wp2 describe the same (virtual) padded geometry in every mode. */
+  int32_t in_dtype, H, W, pad_t, pad_l;
 } tfimm_stem_desc;
 
 TFIMM_API int tfimm_hip_stem_conv_pool(const tfimm_stem_desc* d, void* stream);

@@ -38,7 +38,7 @@ constexpr int kFetch = kGroup * kRowPairs;                         // 16-byte sl
 typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 
 struct StemArgs {
-  const uint4* x;        // [B][Hp][Wp2] pixel pairs (16 bytes: 2 pixels x 4 bf16 channels)
+  const void* x;         // kInPairs: [B][Hp][Wp2] pixel pairs (16 bytes: 2 pixels x 4 bf16 channels); else the raw image
   const bf16_t* wt;      // [64][ldw], k = ky * 32 + pair * 8 + e
   const float* bias;     // [64]
   uint4* out;            // [B][PH][PW][8] x 16 bytes (64 bf16 channels per pixel)
@@ -46,10 +46,75 @@ struct StemArgs {
   int steps;             // = PH: a step is two convolution rows = one pooled row
   int bands, steps_per_band, items;   // items = B * bands
   int dbg;               // TFIMM_STEM_DBG (profiling only): 1 skip pooling, 2 skip the MFMA phase, 4 skip the row prefetch
+  // raw input modes (IN != kInPairs): x is the caller's [B][H][W][3] image (bf16 or float32) and the zero border /
+  // 4th channel / bf16 rounding of tfimm_hip_cast_input_pad happen while the LDS ring is filled
+  int H, W, pad_t, pad_l;
 };
+
+enum { kInPairs = 0, kInBf16Rgb = 1, kInF32Rgb = 2 };
+typedef __attribute__((ext_vector_type(4))) unsigned int stem_u32x4;
+
+// One 16-byte ring slot (a pixel pair) on its way from HBM: the loaded values stay untouched in registers until they
+// are packed for the LDS store a step later (any arithmetic on them earlier would make hipcc wait for the load
+// during the MFMA phase).  Raw modes load from clamped coordinates and zero what lies outside by a mask computed
+// from the coordinates alone.
+template <int IN> struct StemPre;
+template <> struct StemPre<kInPairs> { stem_u32x4 v; };
+template <> struct StemPre<kInBf16Rgb> { uint32_t w0, w1, w2, mask; };     // 12 bytes = two adjacent pixels, + validity / shift
+struct __attribute__((packed, aligned(2))) StemBf16Pair { uint32_t w0, w1, w2; };
+template <> struct StemPre<kInF32Rgb> { uint32_t a0, a1, a2, b0, b1, b2, mask; };
+
+template <int IN>
+__device__ __forceinline__ StemPre<IN> stem_fetch(const StemArgs& p, int b, int r, int pr) {
+  StemPre<IN> o;
+  if constexpr (IN == kInPairs) {
+    const stem_u32x4* xb = reinterpret_cast<const stem_u32x4*>(p.x) + (size_t)b * p.Hp * p.Wp2;
+    o.v = (r < p.Hp && pr < p.Wp2) ? xb[(size_t)r * p.Wp2 + pr] : stem_u32x4{0u, 0u, 0u, 0u};
+  } else {
+    const int y = r - p.pad_t, x0 = 2 * pr - p.pad_l, x1 = x0 + 1;
+    const bool yok = (unsigned)y < (unsigned)p.H;
+    o.mask = ((yok && (unsigned)x0 < (unsigned)p.W) ? 1u : 0u) | ((yok && (unsigned)x1 < (unsigned)p.W) ? 2u : 0u);
+    const size_t rowbase = ((size_t)b * p.H + (size_t)min(max(y, 0), p.H - 1)) * p.W;
+    const size_t e0 = (rowbase + min(max(x0, 0), p.W - 1)) * 3, e1 = (rowbase + min(max(x1, 0), p.W - 1)) * 3;
+    if constexpr (IN == kInBf16Rgb) {
+      // ONE 12-byte load of the two adjacent pixels xb, xb + 1 (xb = x0 clamped into the row); at the row ends the
+      // pair straddles the border and the valid pixel is the other one of the two loaded (bits 2, 3 of mask).
+      // Separate 2-byte loads would be merged by hipcc and un-merged with shifts right behind the load = a wait.
+      const int xb = min(max(x0, 0), p.W - 2);
+      const StemBf16Pair w = *reinterpret_cast<const StemBf16Pair*>(reinterpret_cast<const uint16_t*>(p.x) + (rowbase + xb) * 3);
+      o.w0 = w.w0; o.w1 = w.w1; o.w2 = w.w2;
+      o.mask |= (x0 < xb ? 4u : 0u) | (x0 > xb ? 8u : 0u);
+    } else {
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(p.x);
+      o.a0 = q[e0]; o.a1 = q[e0 + 1]; o.a2 = q[e0 + 2];
+      o.b0 = q[e1]; o.b1 = q[e1 + 1]; o.b2 = q[e1 + 2];
+    }
+  }
+  return o;
+}
+
+template <int IN>
+__device__ __forceinline__ stem_u32x4 stem_pack(const StemPre<IN>& r) {
+  if constexpr (IN == kInPairs) {
+    return r.v;
+  } else if constexpr (IN == kInBf16Rgb) {
+    const uint32_t p0x = r.w0, p0y = r.w1 & 0xffffu;                         // first loaded pixel: (c0 | c1 << 16, c2)
+    const uint32_t p1x = (r.w1 >> 16) | (r.w2 << 16), p1y = r.w2 >> 16;       // second
+    const bool ma = r.mask & 1u, mb = r.mask & 2u, lo = r.mask & 4u, hi = r.mask & 8u;
+    return stem_u32x4{ma ? (hi ? p1x : p0x) : 0u, ma ? (hi ? p1y : p0y) : 0u,
+                      mb ? (lo ? p0x : p1x) : 0u, mb ? (lo ? p0y : p1y) : 0u};
+  } else {
+    // the rounding of tfimm_hip_cast_input (round to nearest even)
+    const uint32_t a0 = f2bf(__uint_as_float(r.a0)), a1 = f2bf(__uint_as_float(r.a1)), a2 = f2bf(__uint_as_float(r.a2));
+    const uint32_t b0 = f2bf(__uint_as_float(r.b0)), b1 = f2bf(__uint_as_float(r.b1)), b2 = f2bf(__uint_as_float(r.b2));
+    const bool ma = r.mask & 1u, mb = r.mask & 2u;
+    return stem_u32x4{ma ? (a0 | (a1 << 16)) : 0u, ma ? a2 : 0u, mb ? (b0 | (b1 << 16)) : 0u, mb ? b2 : 0u};
+  }
+}
 
 // Two workgroups share a CU (78 KB of LDS each) and are in different phases of their steps most of the time, so
 // one's MFMA phase overlaps the other's pooling / barriers.
+template <int IN>
 __global__ void __launch_bounds__(kThreads, 2) stem_pool_kernel(const StemArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sIn = smem;
@@ -87,28 +152,26 @@ __global__ void __launch_bounds__(kThreads, 2) stem_pool_kernel(const StemArgs p
     const int s_end = min(p.steps, s_begin + p.steps_per_band);
     const int s_first = s_begin > 0 ? s_begin - 1 : 0;     // a band below the top recomputes the step above it: its
                                                             // last convolution row is the pooling window's top row
-    const uint4* const xb = p.x + (size_t)b * p.Hp * p.Wp2;
-
     // input rows 4g .. 4g+3 -> ring slots 4 (g % 4) ..; rows / pairs beyond the image are zero
-    auto fetch = [&](int g, int idx) -> uint4 {
+    auto fetch = [&](int g, int idx) __attribute__((always_inline)) {
       const int j = idx / kRowPairs, pr = idx - j * kRowPairs;
-      const int r = kGroup * g + j;
-      return (r < p.Hp && pr < p.Wp2) ? xb[(size_t)r * p.Wp2 + pr] : make_uint4(0u, 0u, 0u, 0u);
+      return stem_fetch<IN>(p, b, kGroup * g + j, pr);
     };
-    auto slot_ptr = [&](int g, int idx) -> uint4* {
-      return reinterpret_cast<uint4*>(sIn + (kGroup * (g & 3)) * kRowB + idx * 16);    // idx = j * kRowPairs + pr
+    auto slot_ptr = [&](int g, int idx) -> stem_u32x4* {
+      return reinterpret_cast<stem_u32x4*>(sIn + (kGroup * (g & 3)) * kRowB + idx * 16);    // idx = j * kRowPairs + pr
     };
     // (every wave is past the previous item's last read of the input ring: that item ended with a barrier + pooling)
     for (int g = s_first; g < s_first + 3; ++g) {
-      for (int idx = tid; idx < kFetch; idx += kThreads) *slot_ptr(g, idx) = fetch(g, idx);
+      for (int idx = tid; idx < kFetch; idx += kThreads) *slot_ptr(g, idx) = stem_pack<IN>(fetch(g, idx));
     }
 
     for (int s = s_first; s < s_end; ++s) {
       // step s: convolution rows 2s, 2s+1 from input rows 4s .. 4s+8 (groups s, s+1, s+2) -> pooled row s.
       // The next step's new rows (group s + 3) are requested now and written to the ring after the arithmetic.
       const bool pf = !(p.dbg & 4);
-      const uint4 pre0 = pf ? fetch(s + 3, tid) : make_uint4(0u, 0u, 0u, 0u);
-      const uint4 pre1 = (pf && tid + kThreads < kFetch) ? fetch(s + 3, tid + kThreads) : make_uint4(0u, 0u, 0u, 0u);
+      StemPre<IN> pre0 = {}, pre1 = {};
+      if (pf) pre0 = fetch(s + 3, tid);
+      if (pf && tid + kThreads < kFetch) pre1 = fetch(s + 3, tid + kThreads);
       __syncthreads();     // groups s .. s+2 are in the ring; the previous step's pooling is done with the conv ring
 
       const int y = 2 * s + mg;                       // this wave's convolution row (may be >= OH: computed, never pooled)
@@ -175,8 +238,8 @@ __global__ void __launch_bounds__(kThreads, 2) stem_pool_kernel(const StemArgs p
         }
       }
       // the prefetched rows: slot group (s + 3) % 4 held group s - 1, which no wave reads any more (barrier above)
-      *slot_ptr(s + 3, tid) = pre0;
-      if (tid + kThreads < kFetch) *slot_ptr(s + 3, tid + kThreads) = pre1;
+      *slot_ptr(s + 3, tid) = stem_pack<IN>(pre0);
+      if (tid + kThreads < kFetch) *slot_ptr(s + 3, tid + kThreads) = stem_pack<IN>(pre1);
       __syncthreads();     // this step's two convolution rows are in LDS
 
       if (s >= s_begin && !(p.dbg & 1)) {
@@ -213,11 +276,15 @@ __global__ void __launch_bounds__(kThreads, 2) stem_pool_kernel(const StemArgs p
 extern "C" int tfimm_hip_stem_conv_pool(const tfimm_stem_desc* d, void* stream) {
   if (!d || !d->x || !d->wt || !d->bias || !d->out || d->batch <= 0 || d->OH <= 0 || d->OW <= 0 || d->OW > kConvW ||
       d->Wp2 <= 0 || d->Wp2 > kRowPairs || d->ldw < 224 || (d->ldw & 7) || d->Hp < 2 * (d->OH - 1) + 7 ||
-      d->Wp2 < d->OW + 3 || ((uintptr_t)d->x & 15) || ((uintptr_t)d->wt & 15) || ((uintptr_t)d->bias & 15) ||
-      ((uintptr_t)d->out & 15))
+      d->Wp2 < d->OW + 3 || ((uintptr_t)d->wt & 15) || ((uintptr_t)d->bias & 15) || ((uintptr_t)d->out & 15) ||
+      d->in_dtype < 0 || d->in_dtype > 2)
     TFIMM_FAIL(TFIMM_EINVAL, "stem_conv_pool: bad arguments (7x7 stride-2 stem, 64 channels, OW <= 112, Wp/2 <= 116)");
+  if (d->in_dtype == 0 ? ((uintptr_t)d->x & 15) != 0
+                       : (d->H <= 0 || d->W < 2 || d->pad_t < 0 || d->pad_l < 0 || ((uintptr_t)d->x & (d->in_dtype == 1 ? 1 : 3))))
+    TFIMM_FAIL(TFIMM_EINVAL, "stem_conv_pool: bad input description");
   StemArgs a;
-  a.x = (const uint4*)d->x; a.wt = (const bf16_t*)d->wt; a.bias = d->bias; a.out = (uint4*)d->out;
+  a.x = d->x; a.wt = (const bf16_t*)d->wt; a.bias = d->bias; a.out = (uint4*)d->out;
+  a.H = d->H; a.W = d->W; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
   a.B = d->batch; a.Hp = d->Hp; a.Wp2 = d->Wp2; a.OH = d->OH; a.OW = d->OW; a.ldw = d->ldw;
   a.PH = (d->OH - 1) / 2 + 1;
   a.PW = (d->OW - 1) / 2 + 1;
@@ -246,10 +313,15 @@ extern "C" int tfimm_hip_stem_conv_pool(const tfimm_stem_desc* d, void* stream) 
   a.dbg = dbg;
   static bool attr_set = false;
   if (!attr_set) {
-    TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)stem_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)stem_pool_kernel<kInPairs>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)stem_pool_kernel<kInBf16Rgb>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)stem_pool_kernel<kInF32Rgb>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     attr_set = true;
   }
   const int grid = a.items < 2 * cus ? a.items : 2 * cus;
-  TFIMM_LAUNCH(stem_pool_kernel, dim3((unsigned)grid), dim3(kThreads), (size_t)kLdsBytes, (hipStream_t)stream, a);
+  const dim3 gd((unsigned)grid), bd(kThreads);
+  if (d->in_dtype == 0) TFIMM_LAUNCH(stem_pool_kernel<kInPairs>, gd, bd, (size_t)kLdsBytes, (hipStream_t)stream, a);
+  else if (d->in_dtype == 1) TFIMM_LAUNCH(stem_pool_kernel<kInBf16Rgb>, gd, bd, (size_t)kLdsBytes, (hipStream_t)stream, a);
+  else TFIMM_LAUNCH(stem_pool_kernel<kInF32Rgb>, gd, bd, (size_t)kLdsBytes, (hipStream_t)stream, a);
   return 0;
 }

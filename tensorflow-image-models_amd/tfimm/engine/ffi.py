@@ -63,6 +63,7 @@ class StemDesc(C.Structure):
         ("x", C.c_void_p), ("wt", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
         ("batch", C.c_int32), ("Hp", C.c_int32), ("Wp2", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32),
         ("ldw", C.c_int32),
+        ("in_dtype", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32),
     ]
 
 

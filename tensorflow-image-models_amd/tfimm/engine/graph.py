@@ -590,6 +590,7 @@ class Plan:
         self.calls: List[Tuple[Callable, tuple]] = []
         self._input_patch = None
         self._input_call = None
+        self._stem_raw = None
         self._gemm_descs = []
         self._gemm_call_index = []
         self._tune_times = {}          # shape key -> {hint: ms} of the last isolated autotune
@@ -722,6 +723,12 @@ class Plan:
                 d.x, d.out = self.tptr(op.inputs[0]), self.tptr(op.output)
                 d.wt, d.bias = self.cptr(op.consts["wt"]), self.cptr(op.consts["bias"])
                 d.batch, d.Hp, d.Wp2, d.OH, d.OW, d.ldw = B, a["Hp"], a["Wp2"], a["OH"], a["OW"], a["ldw"]
+                # the stem can read the caller's RGB image itself (border, 4th channel and rounding applied while its
+                # LDS ring is filled): launch_input() then skips the conversion pass for float / bf16 inputs
+                cast = next((o.attrs for o in prog.ops if o.kind == "cast_input" and o.output == op.inputs[0]), None)
+                if cast is not None and cast["c_in"] == 3 and self.prog.input_shape[2] == 3:
+                    ih, iw, _ = self.prog.input_shape
+                    self._stem_raw = (d, d.x, ih, iw, cast["pad"][0], cast["pad"][2])
                 self._keepalive.append(d)
                 self.calls.append((lib.tfimm_hip_stem_conv_pool, (C.byref(d),)))
             elif k == "maxpool":
@@ -819,7 +826,7 @@ class Plan:
                     evs[i] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     evs[i][0].record()
                 if i == idx:
-                    rc = fn(x_dev.data_ptr(), in_dtype, *self._input_call[1], st)
+                    rc = self.launch_input(x_dev, st)
                 elif fn == "memset":
                     _hip_memset_async(args[0], args[1], stream_ptr)
                     rc = 0
@@ -887,6 +894,32 @@ class Plan:
         return n
 
     # run -------------------------------------------------------------------------------------------
+    def launch_input(self, x_dev, st, norm=None, force_convert=False) -> int:
+        """The input step of the program: convert the caller's image into the engine's padded bf16 layout
+        (tfimm_hip_cast_input[_pad], or tfimm_hip_preprocess_input[_pad] for uint8 + ``norm``) -- or, when the
+        program starts with the fused ResNet stem and the image is RGB float / bf16, just point that kernel at the
+        caller's image (``force_convert`` keeps the separate pass, e.g. to time it)."""
+        import torch
+        idx, out, npix, c_in, c_out = self._input_patch
+        if (x_dev.dtype == torch.uint8) != (norm is not None):
+            raise TypeError("uint8 input needs norm=(mean, std); float input must not pass it")
+        if self._stem_raw is not None:
+            d, padded_ptr, ih, iw, pad_t, pad_l = self._stem_raw
+            raw = (norm is None and not force_convert and x_dev.dtype in (torch.bfloat16, torch.float32)
+                   and os.environ.get("TFIMM_NO_STEM_RAW", "0") != "1")
+            if raw:
+                d.x = x_dev.data_ptr()
+                d.in_dtype = 1 if x_dev.dtype == torch.bfloat16 else 2
+                d.H, d.W, d.pad_t, d.pad_l = ih, iw, pad_t, pad_l
+                return 0
+            d.x, d.in_dtype = padded_ptr, 0
+        if norm is not None:
+            mean = (C.c_float * c_in)(*[float(v) for v in norm[0]])
+            std = (C.c_float * c_in)(*[float(v) for v in norm[1]])
+            return self._input_call_u8[0](x_dev.data_ptr(), *self._input_call_u8[1], mean, std, st)
+        in_dtype = 1 if x_dev.dtype == torch.bfloat16 else 0
+        return self._input_call[0](x_dev.data_ptr(), in_dtype, *self._input_call[1], st)
+
     def run(self, x_dev, stream_ptr: Optional[int] = None, norm=None):
         """Enqueue the whole program on the current torch stream.  ``x_dev``: contiguous cuda
         tensor (B, H, W, C) float32 or bfloat16 -- or uint8 with ``norm = (mean, std)`` (one float per
@@ -897,18 +930,10 @@ class Plan:
         if stream_ptr is None:
             stream_ptr = torch.cuda.current_stream().cuda_stream
         st = C.c_void_p(stream_ptr)
-        idx, out, npix, c_in, c_out = self._input_patch
-        if (x_dev.dtype == torch.uint8) != (norm is not None):
-            raise TypeError("uint8 input needs norm=(mean, std); float input must not pass it")
-        if norm is not None:
-            mean = (C.c_float * c_in)(*[float(v) for v in norm[0]])
-            std = (C.c_float * c_in)(*[float(v) for v in norm[1]])
-        in_dtype = 1 if x_dev.dtype == torch.bfloat16 else 0
+        idx = self._input_patch[0]
         for i, (fn, args) in enumerate(self.calls):
-            if i == idx and norm is not None:
-                rc = self._input_call_u8[0](x_dev.data_ptr(), *self._input_call_u8[1], mean, std, st)
-            elif i == idx:
-                rc = fn(x_dev.data_ptr(), in_dtype, *self._input_call[1], st)
+            if i == idx:
+                rc = self.launch_input(x_dev, st, norm)
             elif fn == "memset":
                 ffi.check(_hip_memset_async(args[0], args[1], stream_ptr), "hipMemsetAsync")
                 continue

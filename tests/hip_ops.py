@@ -170,13 +170,17 @@ def preprocess_input_pad(u8, pad, mean, std):
     return out
 
 
-def stem_conv_pool(xp_pairs, wt, bias, B, Hp, Wp2, OH, OW):
-    """xp_pairs: the zero-bordered 4-channel bf16 image (cast_input_pad); returns (B, PH, PW, 64) bf16."""
+def stem_conv_pool(x, wt, bias, B, Hp, Wp2, OH, OW, raw=None):
+    """x: the zero-bordered 4-channel bf16 image (cast_input_pad), or with raw=(H, W, pad_t, pad_l) the caller's
+    (B, H, W, 3) image in bf16 / float32; returns (B, PH, PW, 64) bf16."""
     PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
     out = torch.empty(B, PH, PW, 64, dtype=torch.bfloat16, device=DEV)
     d = ffi.StemDesc()
-    d.x, d.wt, d.bias, d.out = ptr(xp_pairs), ptr(wt), ptr(bias), ptr(out)
+    d.x, d.wt, d.bias, d.out = ptr(x), ptr(wt), ptr(bias), ptr(out)
     d.batch, d.Hp, d.Wp2, d.OH, d.OW, d.ldw = B, Hp, Wp2, OH, OW, wt.shape[1]
+    if raw is not None:
+        d.in_dtype = 1 if x.dtype == torch.bfloat16 else 2
+        d.H, d.W, d.pad_t, d.pad_l = raw
     ffi.check(lib.tfimm_hip_stem_conv_pool(d, stream()), "stem_conv_pool")
     return out
 

@@ -134,3 +134,27 @@ def test_deferred_uint8_preprocessing_matches_host_path(name):
     replay2 = m(pre(img2)).numpy()
     assert np.array_equal(host, eager) and np.array_equal(host, replay)
     assert np.array_equal(replay2, m(tfimm.create_preprocessing(name)(img2)).numpy())
+
+
+def test_stem_reads_the_callers_image_like_the_padded_copy(monkeypatch):
+    """ResNet's fused stem fed with the caller's float32 / bf16 RGB image (no separate conversion pass) gives the
+    same logits, bit for bit, as the padded-copy path (TFIMM_NO_STEM_RAW=1) -- at the native and at another size."""
+    import torch
+    import tfimm
+    from tfimm.utils.init import synthetic_weights
+    m = tfimm.create_model("resnet18")
+    m.set_weights(synthetic_weights(m))
+    for size in (m.cfg.input_size, (160, 96)):
+        prog = m.program(*size)
+        plan = prog.make_plan(3)
+        assert plan._stem_raw is not None
+        x32 = torch.from_numpy(mc.make_input(m.cfg, 3, size=size)).cuda()
+        for x in (x32, x32.to(torch.bfloat16)):
+            monkeypatch.setenv("TFIMM_NO_STEM_RAW", "1")
+            plan.run(x)
+            a = plan.tensor_view(prog.outputs["logits"]).clone()
+            monkeypatch.delenv("TFIMM_NO_STEM_RAW")
+            plan.run(x)
+            b = plan.tensor_view(prog.outputs["logits"]).clone()
+            torch.cuda.synchronize()
+            assert torch.equal(a, b)

@@ -93,7 +93,7 @@ def main():
 
         def launch():
             if i == idx:
-                return fn(x.data_ptr(), 1, *plan._input_call[1], st)
+                return plan.launch_input(x, st, force_convert=True)     # (time the separate conversion pass)
             return fn(*args, st)
         launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
