@@ -581,6 +581,22 @@ def _():
     return max(_err(_cpu(got), ref), _err(_cpu(got2), ref) / 10), 1e-3
 
 
+@case("mean_rows_wide_and_odd")
+def _():
+    """vector path over several 512-channel groups (2048, 520) and the scalar path (channel count not a multiple of 8)"""
+    import hip_ops as H
+    r = _rng(84)
+    worst = 0.0
+    for shape in [(5, 49, 2048), (3, 7, 520), (2, 144, 1792), (4, 10, 100), (2, 1, 8)]:
+        x = _bf(r.standard_normal(shape))
+        got = H.mean_rows(H.dev_bf16(x), out_f32=True)
+        got2 = H.mean_rows(H.dev_bf16(x), out_f32=False)
+        H.sync()
+        ref = x.mean(1)
+        worst = max(worst, _err(_cpu(got), ref), _err(_cpu(got2), ref) / 10)
+    return worst, 1e-3
+
+
 @case("bcast_rows")
 def _():
     import hip_ops as H
