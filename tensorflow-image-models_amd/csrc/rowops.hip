@@ -955,6 +955,7 @@ __global__ void __launch_bounds__(1024) se_gate_kernel(const float* __restrict__
 #pragma unroll
     for (int im = 0; im < SE_IMG; ++im) s[im] = 0.f;
     const float* wr = w1 + (int64_t)j * C;
+#pragma unroll 4
     for (int c = lane; c < C; c += 64) {
       const float wv = wr[c];
 #pragma unroll
@@ -972,6 +973,8 @@ __global__ void __launch_bounds__(1024) se_gate_kernel(const float* __restrict__
     const float bv = b2 ? b2[c] : 0.f;
 #pragma unroll
     for (int im = 0; im < SE_IMG; ++im) s[im] = bv;
+    // (unrolled: the rd loads of a thread are independent, only the adds are a chain)
+#pragma unroll 8
     for (int j = 0; j < rd; ++j) {
       const float wv = w2[(int64_t)j * C + c];
 #pragma unroll
