@@ -167,8 +167,7 @@ def run_with_events(plan, x_dev, events):
     ffi = plan.ffi
     stream_ptr = torch.cuda.current_stream().cuda_stream
     st = C.c_void_p(stream_ptr)
-    idx, out, npix, c_in, c_out = plan._input_patch
-    in_dtype = 1 if x_dev.dtype == torch.bfloat16 else 0
+    idx = plan._input_patch[0]
     gemm_fn = ffi.lib.tfimm_hip_gemm
     from tfimm.engine.graph import _hip_memset_async
     B = plan.batch

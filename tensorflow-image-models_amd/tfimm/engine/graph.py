@@ -817,7 +817,6 @@ class Plan:
         stream_ptr = torch.cuda.current_stream().cuda_stream
         st = C.c_void_p(stream_ptr)
         idx = self._input_patch[0]
-        in_dtype = 1 if x_dev.dtype == torch.bfloat16 else 0
 
         def forward_timed(call_ids):
             evs = {}
@@ -900,7 +899,7 @@ class Plan:
         program starts with the fused ResNet stem and the image is RGB float / bf16, just point that kernel at the
         caller's image (``force_convert`` keeps the separate pass, e.g. to time it)."""
         import torch
-        idx, out, npix, c_in, c_out = self._input_patch
+        c_in = self._input_patch[3]
         if (x_dev.dtype == torch.uint8) != (norm is not None):
             raise TypeError("uint8 input needs norm=(mean, std); float input must not pass it")
         if self._stem_raw is not None:

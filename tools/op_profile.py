@@ -73,8 +73,7 @@ def main():
         plan.run(x)
     torch.cuda.synchronize()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    idx, out, npix, c_in, c_out = plan._input_patch
-    ops = []
+    idx = plan._input_patch[0]
     oi = 0
     # map calls -> ops (memset calls belong to the following dwconv)
     call_ops = []
