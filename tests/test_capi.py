@@ -67,3 +67,49 @@ def test_gemm_desc_layout_matches_header():
     assert ctypes.sizeof(ffi.GemmDesc) == (6 * 8 + 29 * 4 + 7) // 8 * 8
     # 3 pointers, 4 int32, float, 4 int32 (= 60, padded to 64 for the pointer that follows), 1 pointer
     assert ctypes.sizeof(ffi.AttnDesc) == 64 + 8
+
+
+def _struct_fields(hdr, open_marker, close_marker):
+    body = hdr[hdr.index(open_marker):hdr.index(close_marker)]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        toks = decl.replace("*", " ").split()
+        toks = [t for t in toks if t not in ("const",)]
+        names += [n.strip() for n in " ".join(toks[1:]).split(",")]
+    return names
+
+
+def test_stem_desc_layout_matches_header():
+    hdr = open(HEADER).read()
+    # the stem descriptor is the anonymous struct right in front of "} tfimm_stem_desc;"
+    end = hdr.index("} tfimm_stem_desc;")
+    start = hdr.rindex("typedef struct {", 0, end)
+    names = _struct_fields(hdr[start:end + 1] + "}", "typedef struct {", "}}")
+    assert names == [f[0] for f in ffi.StemDesc._fields_], names
+    assert ctypes.sizeof(ffi.StemDesc) == 4 * 8 + 11 * 4 + 4          # 4 pointers, 11 int32, tail padding
+
+
+def test_new_entry_points_validate_before_any_launch():
+    """stem and uint8 preprocessing reject bad descriptions without touching the GPU."""
+    import torch
+    buf = torch.zeros(4096, dtype=torch.uint8)
+    d = ffi.StemDesc()
+    assert ffi.lib.tfimm_hip_stem_conv_pool(ctypes.byref(d), None) == -1                     # null pointers
+    d.x = d.wt = d.bias = d.out = buf.data_ptr() // 16 * 16 + 16
+    d.batch, d.Hp, d.Wp2, d.OH, d.OW, d.ldw = 1, 229, 115, 112, 113, 256                      # OW > 112
+    assert ffi.lib.tfimm_hip_stem_conv_pool(ctypes.byref(d), None) == -1
+    d.OW, d.Hp = 112, 200                                                                     # too few padded rows
+    assert ffi.lib.tfimm_hip_stem_conv_pool(ctypes.byref(d), None) == -1
+    d.Hp, d.in_dtype = 229, 1                                                                 # raw mode without H / W
+    assert ffi.lib.tfimm_hip_stem_conv_pool(ctypes.byref(d), None) == -1
+    assert b"stem_conv_pool" in ffi.lib.tfimm_hip_last_error()
+    m9 = (ctypes.c_float * 9)(*([0.5] * 9))
+    p = ctypes.c_void_p(buf.data_ptr())
+    assert ffi.lib.tfimm_hip_preprocess_input(p, p, 16, 9, 16, m9, m9, None) == -1            # > 8 channels
+    z3 = (ctypes.c_float * 3)(1.0, 0.0, 1.0)
+    assert ffi.lib.tfimm_hip_preprocess_input(p, p, 16, 3, 4, m9, z3, None) == -1             # std == 0
+    assert ffi.lib.tfimm_hip_preprocess_input_pad(p, p, 1, 4, 4, 5, 0, 0, 0, 0, m9, m9, None) == -1   # c_in > 4
