@@ -8,6 +8,9 @@ Bottleneck.call (:266-292), downsample_conv / downsample_avg (:295-330), make_st
 import math
 from collections import OrderedDict
 
+import torch
+import torch.nn.functional as F
+
 from . import ops
 from .common import BN_EPS, W, finish
 
@@ -19,6 +22,16 @@ def _se(w: W, x, prefix):
     s = ops.activation(s, "relu")
     s = ops.conv2d(s, w(prefix + "/fc2/kernel"), w(prefix + "/fc2/bias"))
     return x * ops.activation(s, "sigmoid")
+
+
+def _eca(w: W, x, prefix):
+    """EcaModule.call (layers/attention.py:120-130): channel means -> zero-padded Conv1D over the channel axis
+    (one filter, no bias; kernel size from the channel count, :105-110) -> sigmoid -> scale."""
+    k = w(prefix + "/conv/kernel").reshape(-1)                          # (k, 1, 1)
+    pad = (k.shape[0] - 1) // 2
+    y = x.mean(dim=(1, 2))                                              # (N, C)
+    y = F.conv1d(F.pad(y[:, None, :], (pad, pad)), k.reshape(1, 1, -1))[:, 0, :]
+    return x * torch.sigmoid(y)[:, None, None, :]
 
 
 def _downsample(w: W, cfg, x, prefix, stride, eps):
@@ -34,7 +47,7 @@ def _downsample(w: W, cfg, x, prefix, stride, eps):
 
 
 def resnet_forward(cfg, weights, x, return_features=False):
-    assert not cfg.aa_layer and cfg.cardinality == 1 and cfg.attn_layer in ("", "se")
+    assert not cfg.aa_layer and cfg.attn_layer in ("", "se", "eca")
     w = W(weights)
     eps = BN_EPS[cfg.norm_layer]
     act = cfg.act_layer
@@ -82,12 +95,14 @@ def resnet_forward(cfg, weights, x, return_features=False):
                 y = ops.conv2d(x, w(p + "/conv1/kernel"))
                 y = ops.activation(w.bn(y, p + "/bn1", eps), act)
                 y = ops.zero_pad2d(y, 1)
-                y = ops.conv2d(y, w(p + "/conv2/kernel"), stride=stride)
+                y = ops.conv2d(y, w(p + "/conv2/kernel"), stride=stride, groups=cfg.cardinality)   # resnet.py:229-236
                 y = ops.activation(w.bn(y, p + "/bn2", eps), act)
                 y = ops.conv2d(y, w(p + "/conv3/kernel"))
                 y = w.bn(y, p + "/bn3", eps)
             if cfg.attn_layer == "se":
                 y = _se(w, y, p + "/se")
+            elif cfg.attn_layer == "eca":
+                y = _eca(w, y, p + "/se")
             if has_down:
                 shortcut = _downsample(w, cfg, shortcut, p, stride, eps)
             x = ops.activation(y + shortcut, act)

@@ -9,13 +9,16 @@ BasicBlock :102-189, Bottleneck :192-292, downsample_avg/_conv :295-330, make_st
   the epilogue; the block's shortcut add + final ReLU ride in the epilogue of its last conv
   (resnet.py:266-292); the 7x7 stem reads the padded-RGB image directly (no im2col).
 
-Not built (raise NotImplementedError at lowering): grouped 3x3 convs (ResNeXt), ECA,
-BlurPool anti-aliasing, GroupNorm.
+ResNet-D shortcuts (average pooling + 1x1 conv) run as one folded 2x2 stride-2 convolution; ResNeXt's grouped 3x3 as a
+dense convolution over the block-diagonal kernel; ECA as mean -> banded GEMM -> sigmoid -> scale.
+Not built (raise NotImplementedError at lowering): BlurPool anti-aliasing, GroupNorm.
 """
 import math
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
+
+import numpy as np
 
 from ..models.config import ModelConfig
 from ..models.model import Model, WeightSpec
@@ -180,18 +183,21 @@ class ResNet(Model):
         return ["stem"] + [f"block_{j}" for j in range(sum(self.cfg.nb_blocks))] + ["features", "logits"]
 
     # ---- lowering ---------------------------------------------------------------------------------------
-    def lower(self, b, H, W, want_features):
+    def check_supported(self) -> None:
+        """Configuration features this engine does not lower (independent of weights and input size)."""
         c = self.cfg
         if c.norm_layer not in _BN_EPS:
             raise NotImplementedError(f"norm_layer={c.norm_layer!r} is outside this engine's scope (GroupNorm).")
         if c.aa_layer:
             raise NotImplementedError("BlurPool2D anti-aliasing (aa_layer) is not built.")
-        if c.cardinality != 1:
-            raise NotImplementedError("grouped 3x3 convolutions (ResNeXt cardinality > 1) are not built yet.")
-        if c.attn_layer not in ("", "se"):
+        if c.attn_layer not in ("", "se", "eca"):
             raise NotImplementedError(f"attn_layer={c.attn_layer!r} is not built yet.")
         if c.global_pool != "avg":
             raise NotImplementedError("only global_pool='avg' is built.")
+
+    def lower(self, b, H, W, want_features):
+        c = self.cfg
+        self.check_supported()
         eps = _BN_EPS[c.norm_layer]
         act = c.act_layer
         x = b.image_input(H, W, c.in_channels)
@@ -220,21 +226,50 @@ class ResNet(Model):
             shortcut = x
             if down:
                 if c.downsample_mode == "avg":
-                    raise NotImplementedError("downsample_mode='avg' (AveragePooling2D shortcut) is not built yet.")
-                pd = (stride + c.down_kernel_size) // 2 - 1                       # resnet.py:319
-                shortcut = b.conv(x, p + "/downsample/0/kernel", stride=stride, padding=pd, bn=p + "/downsample/1",
-                                  bn_eps=eps, cite="resnet.py:315-330")
+                    # resnet.py:295-312 (ResNet-D): AveragePooling2D(2, strides, "same") -> 1x1 conv -> BN.  At even
+                    # sizes "same" adds no padding and every window holds 4 valid elements, so pooling + 1x1 conv IS
+                    # a 2x2 stride-2 convolution with kernel / 4 on every tap (exact in bf16: a power of two) -- one
+                    # GEMM launch, no pooled intermediate.  Odd sizes would need the clipped border windows.
+                    kname = p + "/downsample/1/kernel"
+                    if stride == 1:
+                        shortcut = b.conv(x, kname, bn=p + "/downsample/2", bn_eps=eps, cite="resnet.py:295-312")
+                    else:
+                        if stride != 2 or x.H % 2 or x.W % 2:
+                            raise NotImplementedError("downsample_mode='avg' at an odd feature-map size or stride != 2 "
+                                                      "(border windows of AveragePooling2D 'same') is not built.")
+                        folded = b.define(kname + ":avgpool2x2", np.tile(b.wget(kname) * 0.25, (2, 2, 1, 1)))
+                        shortcut = b.conv(x, folded, stride=2, padding="valid", bn=p + "/downsample/2", bn_eps=eps,
+                                          flops_k=x.C, cite="resnet.py:295-312")
+                else:
+                    pd = (stride + c.down_kernel_size) // 2 - 1                       # resnet.py:319
+                    shortcut = b.conv(x, p + "/downsample/0/kernel", stride=stride, padding=pd, bn=p + "/downsample/1",
+                                      bn_eps=eps, cite="resnet.py:315-330")
             se = c.attn_layer == "se"
-            last = dict(residual=None if se else shortcut, act="" if se else act, act_after_res=not se)
+            gated = c.attn_layer in ("se", "eca")       # the gate sits between the last conv and the shortcut add
+            last = dict(residual=None if gated else shortcut, act="" if gated else act, act_after_res=not gated)
             if c.block == "basic_block":
                 y = b.conv(x, p + "/conv1/kernel", stride=stride, padding=1, bn=p + "/bn1", bn_eps=eps, act=act,
                            cite="resnet.py:168-172")
                 y = b.conv(y, p + "/conv2/kernel", padding=1, bn=p + "/bn2", bn_eps=eps, cite="resnet.py:176-186", **last)
             else:
                 y = b.conv(x, p + "/conv1/kernel", bn=p + "/bn1", bn_eps=eps, act=act, cite="resnet.py:269-271")
-                y = b.conv(y, p + "/conv2/kernel", stride=stride, padding=1, bn=p + "/bn2", bn_eps=eps, act=act,
-                           cite="resnet.py:273-276")
+                k2 = p + "/conv2/kernel"
+                if c.cardinality > 1:
+                    # ResNeXt (resnet.py:229-236, Conv2D(groups=cardinality)): the grouped 3x3 runs as a dense
+                    # convolution over the block-diagonal expansion of its kernel -- exact (the extra products are
+                    # x * 0), at cardinality x the multiply-accumulates; a grouped MFMA kernel is the next step
+                    k2 = b.define(k2 + ":dense", _expand_grouped_kernel(b.wget(k2), c.cardinality))
+                y = b.conv(y, k2, stride=stride, padding=1, bn=p + "/bn2", bn_eps=eps, act=act,
+                           flops_k=9 * y.C // c.cardinality if c.cardinality > 1 else None, cite="resnet.py:273-276")
                 y = b.conv(y, p + "/conv3/kernel", bn=p + "/bn3", bn_eps=eps, cite="resnet.py:280-290", **last)
+            if c.attn_layer == "eca":
+                # EcaModule (layers/attention.py:105-130): channel means -> Conv1D over the channel axis -> sigmoid.
+                # The Conv1D is a banded C x C matrix: one small GEMM (bf16 operands, fp32 gate) with existing kernels.
+                m = b.mean_rows(y, cite="layers/attention.py:122")
+                band = b.define(p + "/se/conv/kernel:band", _eca_band(b.wget(p + "/se/conv/kernel"), y.C))
+                g = b.dense(m, band, act="sigmoid", out_f32=True, cite="layers/attention.py:123-126")
+                y = b.scale_channels(y, g, residual=shortcut, relu_after=True,
+                                     cite="layers/attention.py:129 + resnet.py:289-290")
             if se:
                 m = b.mean_rows(y, out_f32=True, cite="layers/attention.py:67")
                 g = b.se_gate(m, 1, p + "/se/fc1/kernel", p + "/se/fc1/bias", p + "/se/fc2/kernel", p + "/se/fc2/bias",
@@ -257,6 +292,30 @@ class ResNet(Model):
 # ---------------------------------------------------------------------------------------
 # registrations (reference resnet.py:596-1705)
 # ---------------------------------------------------------------------------------------
+def _expand_grouped_kernel(k: np.ndarray, groups: int) -> np.ndarray:
+    """(kh, kw, Cin / groups, Cout) grouped kernel -> (kh, kw, Cin, Cout) with zeros outside the diagonal blocks
+    (tf.keras Conv2D(groups=g): output channel o reads input channels of group o // (Cout / g))."""
+    kh, kw, cg, cout = k.shape
+    og = cout // groups
+    dense = np.zeros((kh, kw, cg * groups, cout), dtype=k.dtype)
+    for g in range(groups):
+        dense[:, :, g * cg:(g + 1) * cg, g * og:(g + 1) * og] = k[:, :, :, g * og:(g + 1) * og]
+    return dense
+
+
+def _eca_band(k: np.ndarray, channels: int) -> np.ndarray:
+    """Conv1D kernel (ks, 1, 1), zero padding (ks - 1) / 2 over the channel axis -> (C, C) matrix B with
+    gate_pre[o] = sum_i mean[i] * B[i][o], B[i][o] = k[i - o + pad] (layers/attention.py:110-125)."""
+    w = np.asarray(k, dtype=np.float32).reshape(-1)
+    pad = (w.shape[0] - 1) // 2
+    band = np.zeros((channels, channels), dtype=np.float32)
+    for j, v in enumerate(w):
+        d = j - pad                                   # input channel i = o + d
+        o = np.arange(max(0, -d), min(channels, channels - d))
+        band[o + d, o] = v
+    return band
+
+
 _D = dict(stem_width=32, stem_type="deep", downsample_mode="avg", first_conv="conv1/0")
 _T = dict(stem_width=32, stem_type="deep_tiered", downsample_mode="avg", first_conv="conv1/0")
 _BC = dict(interpolation="bicubic")

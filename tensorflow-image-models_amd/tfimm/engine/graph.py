@@ -220,7 +220,8 @@ class Builder:
     def conv(self, x: TRef, kernel: str, *, stride=1, padding=0, bn: Optional[str] = None,
              bn_eps=1e-5, bias: Optional[str] = None, act="", residual: Optional[TRef] = None,
              act_after_res=False, a_scale: Optional[TRef] = None, flatten=False,
-             remap=None, res_const=None, res_mod=0, then_maxpool=None, cite="", name="") -> TRef:
+             remap=None, res_const=None, res_mod=0, then_maxpool=None, flops_k: Optional[int] = None,
+             cite="", name="") -> TRef:
         """Conv2D (+ZeroPadding2D / "same") + folded BN / bias + activation + residual.
 
         ``padding``: int (symmetric, as the reference's ZeroPadding2D + VALID), "same"
@@ -260,7 +261,9 @@ class Builder:
         M = OH * OW
         out = p.new_tensor(M, cout, 0 if flatten else OH, 0 if flatten else OW, name=name or kernel)
         consts = {}
-        attrs = dict(M=M, N=cout, K_true=kh * kw * cin, act=act, act_after_res=act_after_res,
+        # K_true feeds the algorithmic FLOP count; ``flops_k`` overrides it where the kernel handed in is an expansion
+        # of the reference's (grouped 3x3 as block-diagonal, pooling folded into the taps)
+        attrs = dict(M=M, N=cout, K_true=flops_k or kh * kw * cin, act=act, act_after_res=act_after_res,
                      out_f32=0, res_mod=res_mod, remap=remap)
         pointwise = (kh == 1 and kw == 1 and stride == 1 and pt == 0 and pl == 0 and x.C == cin)
         # RGB stem / patch embedding with an even stride: the zero padding is written once by the input

@@ -119,6 +119,25 @@ if not is_model("vit_test_model"):
                                 embed_dim=256, nb_blocks=2, nb_heads=8, qkv_bias=False)
 
     @register_model
+    def resnetd_test_model():
+        """ResNet-D: deep stem, AveragePooling2D + 1x1 conv shortcuts (resnet.py:295-312, 473-500)."""
+        return ResNet, ResNetConfig(name="resnetd_test_model", nb_classes=10, input_size=(64, 64), block="bottleneck",
+                                    nb_blocks=(1, 2, 1, 1), nb_channels=(8, 16, 24, 32), stem_width=8, stem_type="deep",
+                                    downsample_mode="avg", first_conv="conv1/0")
+
+    @register_model
+    def resnext_test_model():
+        """ResNeXt: grouped 3x3 convolutions (resnet.py:213, 229-236)."""
+        return ResNet, ResNetConfig(name="resnext_test_model", nb_classes=10, input_size=(64, 64), block="bottleneck",
+                                    nb_blocks=(1, 1, 1, 1), nb_channels=(16, 32, 48, 64), cardinality=4, base_width=16)
+
+    @register_model
+    def ecaresnet_test_model():
+        """ECA channel attention (layers/attention.py:78-130): Conv1D kernel size 3 at 32 channels, 5 at 128."""
+        return ResNet, ResNetConfig(name="ecaresnet_test_model", nb_classes=10, input_size=(64, 64), block="bottleneck",
+                                    nb_blocks=(1, 1, 1, 1), nb_channels=(8, 16, 24, 32), attn_layer="eca")
+
+    @register_model
     def seresnet_test_model():
         return ResNet, ResNetConfig(name="seresnet_test_model", nb_classes=10, input_size=(32, 32), block="bottleneck",
                                     nb_blocks=(1, 1, 1, 1), nb_channels=(8, 16, 16, 32), attn_layer="se", se_ratio=0.25)

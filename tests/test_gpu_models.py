@@ -10,11 +10,13 @@ pytestmark = pytest.mark.gpu
 MINIS = ["vit_test_model", "deit_test_model", "vit_hd64_test_model", "resnet_test_model_1", "resnet_test_model_2",
          "resnet50_mini_test_model", "seresnet_test_model", "swin_test_model", "swin_shift_test_model",
          "efficientnet_test_model", "efficientnet_same_test_model", "convnext_odd_test_model", "convnext_wide_test_model",
-         "cait_hd48_test_model", "cait_hd32_test_model"]
+         "cait_hd48_test_model", "cait_hd32_test_model", "resnetd_test_model", "resnext_test_model",
+         "ecaresnet_test_model"]
 FULL = [("vit_tiny_patch16_224", 2), ("deit_tiny_distilled_patch16_224", 2), ("resnet18", 2), ("resnet50", 2),
         ("vit_base_patch16_224", 1), ("swin_tiny_patch4_window7_224", 2), ("efficientnet_b0", 2),
         ("swin_base_patch4_window7_224", 1), ("efficientnet_b4", 1), ("efficientnet_v2_b0", 2), ("mobilenet_v2_100", 2), ("convnext_tiny", 2),
-        ("convnext_base_384_in22ft1k", 1), ("cait_xxs24_224", 2), ("cait_s24_224", 1), ("cait_m36_384", 1)]
+        ("convnext_base_384_in22ft1k", 1), ("cait_xxs24_224", 2), ("cait_s24_224", 1), ("cait_m36_384", 1), ("resnet50d", 2),
+        ("seresnet152d", 1), ("resnext50_32x4d", 1), ("ecaresnet50d", 1)]
 
 
 @pytest.mark.parametrize("name", MINIS)

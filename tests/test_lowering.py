@@ -1,0 +1,116 @@
+"""Layer-program lowering decisions that can be checked without a GPU: which models get the fused ResNet stem
+(tfimm_hip_stem_conv_pool) and which keep convolution + max pooling as two ops (engine/graph.py, Builder.conv)."""
+import pytest
+
+import test_architectures  # noqa: F401  (registers the miniature configs)
+import tfimm
+from tfimm.utils.init import synthetic_weights
+
+
+def _kinds(name, size=None, **kw):
+    m = tfimm.create_model(name, **kw)
+    m.set_weights(synthetic_weights(m))
+    prog = m.program(*(size or m.cfg.input_size))
+    return [op.kind for op in prog.ops], prog
+
+
+def test_plain_resnet_stem_is_one_op():
+    kinds, prog = _kinds("resnet50")
+    assert kinds[:3] == ["cast_input", "stem_pool", "gemm"] and "maxpool" not in kinds
+    stem = prog.ops[1]
+    # resnet.py:505-512, 538-540: 224 -> conv 112 -> pool 56; the padded pair view the kernel expects
+    assert (stem.attrs["OH"], stem.attrs["OW"], stem.attrs["Hp"], stem.attrs["Wp2"]) == (112, 112, 229, 115)
+    assert prog.tensors[stem.output].H == 56 and prog.tensors[stem.output].C == 64
+    # the convolution's flops still count (bench.py's model_tflops / gflops_per_image)
+    assert abs(prog.flops_per_image() / 1e9 - 8.178) < 0.01
+
+
+def test_other_sizes_and_the_112_column_limit():
+    kinds, prog = _kinds("resnet18", size=(160, 128))
+    assert kinds[1] == "stem_pool" and (prog.ops[1].attrs["OH"], prog.ops[1].attrs["OW"]) == (80, 64)
+    kinds, _ = _kinds("resnet18", size=(224, 448))         # 224 output columns: two ops
+    assert kinds[1:3] == ["gemm", "maxpool"]
+
+
+@pytest.mark.parametrize("name", ["resnet26d", "resnet26t", "resnetrs50"])
+def test_deep_stems_stay_unfused_and_avg_down_is_one_folded_conv(name):
+    """ResNet-D shortcuts (AveragePooling2D(2, 2, 'same') + 1x1 conv, resnet.py:295-312) lower to ONE 2x2 stride-2
+    convolution whose taps are the 1x1 kernel / 4; deep stems never take the fused 7x7 stem kernel."""
+    kinds, prog = _kinds(name)
+    assert "stem_pool" not in kinds and kinds.count("maxpool") <= 1
+    folded = [op for op in prog.ops if op.kind == "gemm" and op.attrs.get("KH") == 2 and op.attrs.get("stride") == 2]
+    assert len(folded) == 3                                   # the three strided stage transitions
+    for op in folded:
+        assert op.attrs["K"] == 4 * op.attrs["Cin"] and op.attrs["OH"] * 2 == op.attrs["H"]
+
+
+def test_avg_down_at_odd_sizes_is_refused():
+    m = tfimm.create_model("resnet26d")
+    m.set_weights(synthetic_weights(m))
+    with pytest.raises(NotImplementedError, match="odd"):
+        m.program(200, 200)              # 200 -> stem 100 -> pool 50 -> 25 (odd) at the next transition
+
+
+def test_environment_switch_keeps_the_two_op_path(monkeypatch):
+    monkeypatch.setenv("TFIMM_NO_STEM_FUSION", "1")
+    kinds, _ = _kinds("resnet18")
+    assert kinds[1:3] == ["gemm", "maxpool"]
+
+
+def test_non_rgb_input_keeps_the_conversion_pass():
+    """in_channels = 1: the stem is still fused (4 stored channels), but only RGB images are read raw by it."""
+    kinds, prog = _kinds("resnet18", in_channels=1)
+    assert kinds[1] == "stem_pool" and prog.input_shape[2] == 1
+
+
+def test_avg_pool_then_1x1_conv_equals_the_folded_2x2_conv():
+    """the identity the ResNet-D lowering relies on, checked with the oracle's TF-semantics ops"""
+    import numpy as np
+    import torch
+    from oracle import ops
+    r = np.random.default_rng(3)
+    x = torch.from_numpy(r.standard_normal((2, 8, 6, 5)).astype(np.float32))
+    w = r.standard_normal((1, 1, 5, 7)).astype(np.float32)
+    ref = ops.conv2d(ops.avg_pool2d_same(x, 2, 2), torch.from_numpy(w))
+    folded = ops.conv2d(x, torch.from_numpy(np.tile(w * 0.25, (2, 2, 1, 1))), stride=2)
+    assert ref.shape == folded.shape == (2, 4, 3, 7)
+    assert float((ref - folded).abs().max()) < 1e-5
+
+
+def test_oracle_runs_the_resnet_d_mini():
+    import numpy as np
+    import model_checks as mc
+    import oracle
+    m = tfimm.create_model("resnetd_test_model")
+    w = synthetic_weights(m)
+    y = oracle.forward(m.cfg, w, mc.make_input(m.cfg, 2))
+    assert y.shape == (2, 10) and np.isfinite(y).all()
+
+
+def test_resnext_and_eca_lower_to_existing_ops_and_the_oracle_runs_them():
+    import numpy as np
+    import model_checks as mc
+    import oracle
+    kinds, prog = _kinds("resnext_test_model")
+    assert kinds[1] == "stem_pool"
+    grouped = [op for op in prog.ops if op.kind == "gemm" and op.attrs.get("KH") == 3]
+    # algorithmic K of a grouped 3x3 = 9 * Cin / groups although the dense expansion multiplies 9 * Cin
+    assert all(op.attrs["K_true"] * 4 == 9 * op.attrs["Cin"] for op in grouped)
+    kinds, _ = _kinds("ecaresnet_test_model")
+    assert kinds.count("scale_channels") == 4 and kinds.count("mean_rows") == 5     # 4 gates + the head pooling
+    for name in ("resnext_test_model", "ecaresnet_test_model"):
+        m = tfimm.create_model(name)
+        y = oracle.forward(m.cfg, synthetic_weights(m), mc.make_input(m.cfg, 2))
+        assert y.shape == (2, 10) and np.isfinite(y).all()
+
+
+def test_which_registered_resnets_are_still_refused():
+    """of the reference's registered ResNet-module configurations only the GroupNorm and the BlurPool one are not
+    built (checked on the configurations: building all ~70 programs would take minutes)"""
+    refused = []
+    for name in tfimm.list_models(module="resnet"):
+        try:
+            tfimm.create_model(name).check_supported()
+        except NotImplementedError:
+            refused.append(name)
+    assert sorted(refused) == ["resnet50_gn", "resnetblur50"], refused
