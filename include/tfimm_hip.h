@@ -323,6 +323,48 @@ TFIMM_API int tfimm_hip_scale_channels(const void* x, const float* gate, const v
 TFIMM_API int tfimm_hip_patch_merge_ln(const void* x, void* y, const float* gamma, const float* beta,
                              int B, int H, int W, int C, float eps, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * tfimm_hip_attention_probs: probs[b][h][i][j] = softmax_j(scale * q[b,i,h,:] . k[b,j,h,:]) in fp32 --
+ * the attention map ViTMultiHeadAttention.call returns as features["attn"] when return_features=True
+ * (vit.py:160-163; ViT.forward_features stores it as "block_<j>/attn", vit.py:447-450).  qkv: bf16
+ * [B*n_tokens][3*heads*hd] as tfimm_hip_attention reads it.  Feature path only: the plain forward never
+ * materialises the map.
+ * ------------------------------------------------------------------------------------- */
+TFIMM_API int tfimm_hip_attention_probs(const void* qkv, void* probs, int B, int n_tokens, int heads, int hd,
+                              float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * tfimm_hip_group_norm: GroupNormalization over NHWC (layers/norm.py:37-165, group_normalize): per (image, group)
+ * mean / population variance over (H, W, C/groups), y = x*inv + (beta - mean*inv), inv = rsqrt(var+eps)*gamma
+ * (tf.nn.batch_normalization), then act, then (+ residual, act_after_res) when residual != NULL -- the
+ * norm + activation + shortcut add of a ResNet block whose norm_layer is "group_norm" (resnet.py:269-290).
+ * x / residual / y: bf16 [B][rows][C]; gamma / beta: fp32 [C]; stats_ws: fp32 [B][groups][2] scratch (zeroed here).
+ * ------------------------------------------------------------------------------------- */
+TFIMM_API int tfimm_hip_group_norm(const void* x, const float* gamma, const float* beta, const void* residual, void* y,
+                         float* stats_ws, int B, int rows, int C, int groups, float eps, int act,
+                         int act_after_res, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * tfimm_hip_blur_pool: BlurPool2D(kernel_size=3, stride) (layers/blurpool.py:5-66): tf.pad(REFLECT) by
+ * p = (3 + stride) / 2 - 1, then the depthwise [1 2 1] x [1 2 1] / 16 filter at `stride`, VALID.
+ * x: bf16 [B][H][W][C] -> y: bf16 [B][OH][OW][C], OH = (H + 2p - 3) / stride + 1.
+ * ------------------------------------------------------------------------------------- */
+TFIMM_API int tfimm_hip_blur_pool(const void* x, void* y, int B, int H, int W, int C, int stride, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * tfimm_hip_avg_pool: AveragePooling2D(pool_size=k, strides=stride, padding="same") (resnet.py:299-301):
+ * OH = ceil(H / stride); windows clipped at the border average over their VALID elements only.
+ * ------------------------------------------------------------------------------------- */
+TFIMM_API int tfimm_hip_avg_pool(const void* x, void* y, int B, int H, int W, int C, int k, int stride, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * tfimm_hip_eca_gate: gate[b][c] = gate_act( sum_t w[t] * mean[b][c + t - (k-1)/2] ), zero padded over the
+ * channel axis, mean = sums * inv_count -- EcaModule.call between the channel mean and the final multiply
+ * (ZeroPadding1D + Conv1D(1, k, no bias) + gate, layers/attention.py:110-126).  All fp32; w: [k].
+ * ------------------------------------------------------------------------------------- */
+TFIMM_API int tfimm_hip_eca_gate(const float* sums, float inv_count, const float* w, float* gate, int B, int C, int k,
+                       int gate_act, void* stream);
+
 /* hipMemsetAsync on the library's own HIP runtime (zeroing accumulation buffers such as the
  * dwconv sum_out) -- avoids a second runtime instance being loaded by the host language. */
 TFIMM_API int tfimm_hip_memset_async(void* dst, int value, size_t bytes, void* stream);

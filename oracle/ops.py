@@ -10,8 +10,10 @@ restate the published semantics of each op on top of torc
 tensors, NHWC / HWIO layouts exactly as the reference uses them.  They are pinned by
 tests/test_oracle_ops.py against hand-computed known answers and independent numpy
 formulations; the model-level restatements in this package are additionally pinned by
-running the reference's OWN model code over these ops (oracle/tf_shim, see
-oracle/README.md).
+running the reference's OWN model code (/root/reference/tfimm, unmodified) over these ops
+through the stand-in TensorFlow of oracle/tf_shim: oracle/tools/make_reference_golden.py writes
+its outputs to tests/golden/forward_golden.npz and tests/test_golden.py holds every restatement
+to them at 1e-5 (see oracle/README.md for what that does and does not pin).
 
 Every function cites the reference call sites it serves.
 """
@@ -54,33 +56,41 @@ def same_pad_amounts(size: int, k: int, s: int, d: int = 1) -> Tuple[int, int]:
 
 
 # ---- convolutions -----------------------------------------------------------------------------
-def conv2d(x: T, kernel: T, bias: Optional[T] = None, stride: int = 1, padding: str = "valid",
-           groups: int = 1) -> T:
+def _pair(v) -> Tuple[int, int]:
+    return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+def conv2d(x: T, kernel: T, bias: Optional[T] = None, stride=1, padding: str = "valid",
+           groups: int = 1, dilation=1) -> T:
     """tf.keras.layers.Conv2D: NHWC input, HWIO kernel, cross-correlation
     (vit/resnet/efficientnet conv call sites; transformers.py:155-163)."""
     kh, kw = kernel.shape[0], kernel.shape[1]
+    sh, sw = _pair(stride)
+    dh, dw = _pair(dilation)
     if padding == "same":
-        pt, pb = same_pad_amounts(x.shape[1], kh, stride)
-        pl, pr = same_pad_amounts(x.shape[2], kw, stride)
+        pt, pb = same_pad_amounts(x.shape[1], kh, sh, dh)
+        pl, pr = same_pad_amounts(x.shape[2], kw, sw, dw)
         x = zero_pad2d(x, ((pt, pb), (pl, pr)))
     elif padding != "valid":
         raise ValueError(padding)
     w = kernel.permute(3, 2, 0, 1).contiguous()  # HWIO -> OIHW
-    y = F.conv2d(x.permute(0, 3, 1, 2), w, bias, stride=stride, groups=groups)
+    y = F.conv2d(x.permute(0, 3, 1, 2), w, bias, stride=(sh, sw), dilation=(dh, dw), groups=groups)
     return y.permute(0, 2, 3, 1).contiguous()
 
 
-def depthwise_conv2d(x: T, kernel: T, bias: Optional[T] = None, stride: int = 1,
-                     padding: str = "valid") -> T:
+def depthwise_conv2d(x: T, kernel: T, bias: Optional[T] = None, stride=1,
+                     padding: str = "valid", dilation=1) -> T:
     """tf.keras.layers.DepthwiseConv2D: kernel (kh, kw, C, 1) (layers/conv.py:91-148)."""
     kh, kw, c, mult = kernel.shape
     assert mult == 1
+    sh, sw = _pair(stride)
+    dh, dw = _pair(dilation)
     if padding == "same":
-        pt, pb = same_pad_amounts(x.shape[1], kh, stride)
-        pl, pr = same_pad_amounts(x.shape[2], kw, stride)
+        pt, pb = same_pad_amounts(x.shape[1], kh, sh, dh)
+        pl, pr = same_pad_amounts(x.shape[2], kw, sw, dw)
         x = zero_pad2d(x, ((pt, pb), (pl, pr)))
     w = kernel.permute(2, 3, 0, 1).contiguous()  # (C, 1, kh, kw)
-    y = F.conv2d(x.permute(0, 3, 1, 2), w, bias, stride=stride, groups=c)
+    y = F.conv2d(x.permute(0, 3, 1, 2), w, bias, stride=(sh, sw), dilation=(dh, dw), groups=c)
     return y.permute(0, 2, 3, 1).contiguous()
 
 
@@ -103,6 +113,20 @@ def layer_norm(x: T, gamma: T, beta: T, eps: float) -> T:
 def batch_norm(x: T, gamma: T, beta: T, mean: T, var: T, eps: float) -> T:
     """Keras BatchNormalization at training=False: gamma*(x-mean)*rsqrt(var+eps)+beta."""
     return (x - mean) * torch.rsqrt(var + eps) * gamma + beta
+
+
+def group_norm(x: T, gamma: T, beta: T, groups: int, eps: float) -> T:
+    """layers/norm.py:37-107 group_normalize on N..C input: reshape to N..GS, population moments over every axis
+    but N and G (tf.nn.moments), tf.nn.batch_normalization with per-channel gamma / beta."""
+    shape = x.shape
+    c = shape[-1]
+    xg = x.reshape(*shape[:-1], groups, c // groups)
+    dims = tuple(range(1, xg.dim() - 2)) + (xg.dim() - 1,)
+    mean = xg.mean(dim=dims, keepdim=True)
+    var = ((xg - mean) ** 2).mean(dim=dims, keepdim=True)
+    inv = torch.rsqrt(var + eps) * gamma.reshape(groups, c // groups)
+    y = xg * inv + (beta.reshape(groups, c // groups) - mean * inv)
+    return y.reshape(shape)
 
 
 # ---- activations (layers/factory.py:6-13) ---------------------------------------------------------
@@ -129,10 +153,20 @@ def softmax(x: T, axis: int = -1) -> T:
 
 
 # ---- pooling ----------------------------------------------------------------------------------------
-def max_pool2d(x: T, k: int, stride: int) -> T:
-    """tf.keras.layers.MaxPool2D(pool_size=k, strides=stride), VALID, NHWC (resnet.py:539)."""
+def max_pool2d(x: T, k: int, stride: int, padding: str = "valid") -> T:
+    """tf.keras.layers.MaxPool2D(pool_size=k, strides=stride), NHWC (resnet.py:539).  "same" pads with
+    -inf, i.e. border windows take the maximum over their valid elements."""
+    if padding == "same":
+        pt, pb = same_pad_amounts(x.shape[1], k, stride)
+        pl, pr = same_pad_amounts(x.shape[2], k, stride)
+        x = F.pad(x, (0, 0, pl, pr, pt, pb), value=float("-inf"))
     y = F.max_pool2d(x.permute(0, 3, 1, 2), k, stride)
     return y.permute(0, 2, 3, 1).contiguous()
+
+
+def avg_pool2d_valid(x: T, k: int, stride: int) -> T:
+    """AveragePooling2D(padding="valid")."""
+    return F.avg_pool2d(x.permute(0, 3, 1, 2), k, stride).permute(0, 2, 3, 1).contiguous()
 
 
 def avg_pool2d_same(x: T, k: int, stride: int) -> T:
@@ -145,6 +179,18 @@ def avg_pool2d_same(x: T, k: int, stride: int) -> T:
     s = F.avg_pool2d(xp, k, stride) * (k * k)
     n = F.avg_pool2d(ones, k, stride) * (k * k)
     return (s / n).permute(0, 2, 3, 1).contiguous()
+
+
+def blur_pool2d(x: T, stride: int, kernel_size: int = 3) -> T:
+    """layers/blurpool.py:5-66 BlurPool2D: tf.pad(REFLECT) by (k + stride) // 2 - 1, then the binomial depthwise
+    filter ([1 2 1] x [1 2 1] / 16 for k = 3) at `stride`, VALID."""
+    assert kernel_size == 3
+    p = (kernel_size + stride) // 2 - 1
+    xp = F.pad(x.permute(0, 3, 1, 2), (p, p, p, p), mode="reflect") if p else x.permute(0, 3, 1, 2)
+    c = x.shape[-1]
+    bk = torch.tensor([[1., 2., 1.], [2., 4., 2.], [1., 2., 1.]]) / 16.0
+    y = F.conv2d(xp, bk.reshape(1, 1, 3, 3).repeat(c, 1, 1, 1), stride=stride, groups=c)
+    return y.permute(0, 2, 3, 1).contiguous()
 
 
 def global_avg_pool(x: T) -> T:

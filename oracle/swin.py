@@ -6,7 +6,9 @@ PatchMerging.call (:348-362), window_partition / window_reverse (:72-108) litera
 partition, gather of the bias table, the -100 mask built from slices, reverse, roll back.
 
 Parity note: the reference's own timm comparison is disabled for Swin (tests/test_timm.py:29-30),
-so this restatement is pinned by the reference's model code itself run over oracle/tf_shim.
+so this restatement is pinned by the reference's model code itself, run over the stand-in TensorFlow of
+oracle/tf_shim (oracle/tools/make_reference_golden.py -> tests/golden/forward_golden.npz: swin_test_model,
+swin_shift_test_model incl. every feature, swin_tiny / swin_base logits; tests/test_golden.py).
 """
 from collections import OrderedDict
 

@@ -9,9 +9,11 @@ BasicBlock :102-189, Bottleneck :192-292, downsample_avg/_conv :295-330, make_st
   the epilogue; the block's shortcut add + final ReLU ride in the epilogue of its last conv
   (resnet.py:266-292); the 7x7 stem reads the padded-RGB image directly (no im2col).
 
-ResNet-D shortcuts (average pooling + 1x1 conv) run as one folded 2x2 stride-2 convolution; ResNeXt's grouped 3x3 as a
-dense convolution over the block-diagonal kernel; ECA as mean -> banded GEMM -> sigmoid -> scale.
-Not built (raise NotImplementedError at lowering): BlurPool anti-aliasing, GroupNorm.
+ResNet-D shortcuts (average pooling + 1x1 conv) run as one folded 2x2 stride-2 convolution at even sizes and as
+tfimm_hip_avg_pool + 1x1 conv at odd ones; ResNeXt's grouped 3x3 as a dense convolution over the block-diagonal kernel;
+ECA as fp32 channel means -> tfimm_hip_eca_gate -> scale; GroupNorm models (norm_layer="group_norm") keep the
+normalisation as its own kernel behind each convolution (tfimm_hip_group_norm, with the activation and the shortcut add
+fused); BlurPool anti-aliasing is tfimm_hip_blur_pool.
 """
 import math
 from collections import OrderedDict
@@ -78,12 +80,17 @@ class ResNetConfig(ModelConfig):
             self.test_input_size = self.input_size
 
 
-def _bn_specs(s, prefix, c, zero_init=False):
+_GN_GROUPS, _GN_EPS = 32, 1e-5      # GroupNormalization defaults (layers/norm.py:128-139, layers/factory.py:55-56)
+
+
+def _norm_specs(s, prefix, c, norm_layer="batch_norm", zero_init=False):
+    """Variables of one norm layer: BatchNormalization has four, GroupNormalization gamma / beta only."""
     z = "zeros" if zero_init else ""
     s[prefix + "/gamma"] = WeightSpec((c,), "gamma", z)
     s[prefix + "/beta"] = WeightSpec((c,), "beta")
-    s[prefix + "/moving_mean"] = WeightSpec((c,), "mean")
-    s[prefix + "/moving_variance"] = WeightSpec((c,), "var", z)
+    if norm_layer in _BN_EPS:
+        s[prefix + "/moving_mean"] = WeightSpec((c,), "mean")
+        s[prefix + "/moving_variance"] = WeightSpec((c,), "var", z)
 
 
 class ResNet(Model):
@@ -121,6 +128,10 @@ class ResNet(Model):
     def weight_specs(self):
         c = self.cfg
         s = OrderedDict()
+
+        def _bn_specs(s_, prefix, ch_, zero_init=False):
+            _norm_specs(s_, prefix, ch_, c.norm_layer, zero_init)
+
         if c.stem_type in ("deep", "deep_tiered"):
             ch = (3 * (c.stem_width // 4), c.stem_width) if c.stem_type == "deep_tiered" else (c.stem_width, c.stem_width)
             s["conv1/0/kernel"] = WeightSpec((3, 3, c.in_channels, ch[0]), "conv")
@@ -186,10 +197,10 @@ class ResNet(Model):
     def check_supported(self) -> None:
         """Configuration features this engine does not lower (independent of weights and input size)."""
         c = self.cfg
-        if c.norm_layer not in _BN_EPS:
-            raise NotImplementedError(f"norm_layer={c.norm_layer!r} is outside this engine's scope (GroupNorm).")
-        if c.aa_layer:
-            raise NotImplementedError("BlurPool2D anti-aliasing (aa_layer) is not built.")
+        if c.norm_layer not in _BN_EPS and c.norm_layer != "group_norm":
+            raise NotImplementedError(f"norm_layer={c.norm_layer!r} is not built.")
+        if c.aa_layer not in ("", "blur_pool"):
+            raise NotImplementedError(f"aa_layer={c.aa_layer!r} is not built.")
         if c.attn_layer not in ("", "se", "eca"):
             raise NotImplementedError(f"attn_layer={c.attn_layer!r} is not built yet.")
         if c.global_pool != "avg":
@@ -198,23 +209,41 @@ class ResNet(Model):
     def lower(self, b, H, W, want_features):
         c = self.cfg
         self.check_supported()
-        eps = _BN_EPS[c.norm_layer]
+        gn = c.norm_layer == "group_norm"
+        eps = _GN_EPS if gn else _BN_EPS[c.norm_layer]
         act = c.act_layer
+
+        def conv_norm(x, kernel, norm, *, act="", residual=None, act_after=False, cite="", **kw):
+            """Conv2D -> norm -> activation (-> + shortcut -> activation).  BatchNorm folds into the convolution's
+            weights and everything rides in its epilogue; GroupNorm statistics depend on the convolution's whole
+            output, so it runs as its own kernel with the activation / shortcut add fused into it instead."""
+            if not gn:
+                return b.conv(x, kernel, bn=norm, bn_eps=eps, act=act, residual=residual, act_after_res=act_after,
+                              cite=cite, **kw)
+            y = b.conv(x, kernel, cite=cite, **kw)
+            if residual is not None:        # norm -> + shortcut -> act  (resnet.py:281-290)
+                return b.group_norm(y, norm, _GN_GROUPS, eps, residual=residual, act_after=act,
+                                    cite="layers/norm.py:37-165")
+            return b.group_norm(y, norm, _GN_GROUPS, eps, act=act, cite="layers/norm.py:37-165")
+
         x = b.image_input(H, W, c.in_channels)
         # ---- stem (resnet.py:466-512, 572-575)
+        fused_pool = False
         if c.stem_type in ("deep", "deep_tiered"):
-            x = b.conv(x, "conv1/0/kernel", stride=2, padding=1, bn="conv1/1", bn_eps=eps, act=act, cite="resnet.py:473-481")
-            x = b.conv(x, "conv1/3/kernel", padding="same", bn="conv1/4", bn_eps=eps, act=act, cite="resnet.py:482-490")
-            x = b.conv(x, "conv1/6/kernel", padding="same", bn="bn1", bn_eps=eps, act=act, cite="resnet.py:491-500,513-514")
-            fused_pool = False
+            x = conv_norm(x, "conv1/0/kernel", "conv1/1", stride=2, padding=1, act=act, cite="resnet.py:473-481")
+            x = conv_norm(x, "conv1/3/kernel", "conv1/4", padding="same", act=act, cite="resnet.py:482-490")
+            x = conv_norm(x, "conv1/6/kernel", "bn1", padding="same", act=act, cite="resnet.py:491-500,513-514")
         else:
             # plain stem: convolution and the pooling behind it go to the builder together (one kernel when it can)
-            fused_pool = not c.replace_stem_pool
-            x = b.conv(x, "conv1/kernel", stride=2, padding=3, bn="bn1", bn_eps=eps, act=act,
-                       then_maxpool=(3, 2, 1) if fused_pool else None, cite="resnet.py:505-514,538-540")
+            fused_pool = not c.replace_stem_pool and not c.aa_layer and not gn
+            x = conv_norm(x, "conv1/kernel", "bn1", stride=2, padding=3, act=act,
+                          cite="resnet.py:505-514,538-540", **({"then_maxpool": (3, 2, 1)} if fused_pool else {}))
         # ---- stem pooling (resnet.py:517-540)
         if c.replace_stem_pool:
-            x = b.conv(x, "maxpool/0/kernel", stride=2, padding=1, bn="maxpool/1", bn_eps=eps, act=act, cite="resnet.py:520-530")
+            x = conv_norm(x, "maxpool/0/kernel", "maxpool/1", stride=2, padding=1, act=act, cite="resnet.py:520-530")
+        elif c.aa_layer:
+            x = b.maxpool(x, 3, 1, 1, cite="resnet.py:533-534")
+            x = b.blur_pool(x, 2, cite="resnet.py:535 + layers/blurpool.py:52-60")
         elif not fused_pool:
             x = b.maxpool(x, 3, 2, 1, cite="resnet.py:538-540")
         if want_features:
@@ -226,48 +255,54 @@ class ResNet(Model):
             shortcut = x
             if down:
                 if c.downsample_mode == "avg":
-                    # resnet.py:295-312 (ResNet-D): AveragePooling2D(2, strides, "same") -> 1x1 conv -> BN.  At even
+                    # resnet.py:295-312 (ResNet-D): AveragePooling2D(2, stride, "same") -> 1x1 conv -> norm.  At even
                     # sizes "same" adds no padding and every window holds 4 valid elements, so pooling + 1x1 conv IS
                     # a 2x2 stride-2 convolution with kernel / 4 on every tap (exact in bf16: a power of two) -- one
-                    # GEMM launch, no pooled intermediate.  Odd sizes would need the clipped border windows.
+                    # GEMM launch, no pooled intermediate.  At odd sizes the last row / column of windows is clipped
+                    # and averages over 2 or 1 elements: explicit pooling kernel, then the 1x1 convolution.
                     kname = p + "/downsample/1/kernel"
                     if stride == 1:
-                        shortcut = b.conv(x, kname, bn=p + "/downsample/2", bn_eps=eps, cite="resnet.py:295-312")
-                    else:
-                        if stride != 2 or x.H % 2 or x.W % 2:
-                            raise NotImplementedError("downsample_mode='avg' at an odd feature-map size or stride != 2 "
-                                                      "(border windows of AveragePooling2D 'same') is not built.")
+                        shortcut = conv_norm(x, kname, p + "/downsample/2", cite="resnet.py:295-312")
+                    elif stride == 2 and x.H % 2 == 0 and x.W % 2 == 0:
                         folded = b.define(kname + ":avgpool2x2", np.tile(b.wget(kname) * 0.25, (2, 2, 1, 1)))
-                        shortcut = b.conv(x, folded, stride=2, padding="valid", bn=p + "/downsample/2", bn_eps=eps,
-                                          flops_k=x.C, cite="resnet.py:295-312")
+                        shortcut = conv_norm(x, folded, p + "/downsample/2", stride=2, padding="valid", flops_k=x.C,
+                                             cite="resnet.py:295-312")
+                    else:
+                        pooled = b.avg_pool(x, 2, stride, cite="resnet.py:299-301")
+                        shortcut = conv_norm(pooled, kname, p + "/downsample/2", cite="resnet.py:304-312")
                 else:
                     pd = (stride + c.down_kernel_size) // 2 - 1                       # resnet.py:319
-                    shortcut = b.conv(x, p + "/downsample/0/kernel", stride=stride, padding=pd, bn=p + "/downsample/1",
-                                      bn_eps=eps, cite="resnet.py:315-330")
+                    shortcut = conv_norm(x, p + "/downsample/0/kernel", p + "/downsample/1", stride=stride, padding=pd,
+                                         cite="resnet.py:315-330")
             se = c.attn_layer == "se"
-            gated = c.attn_layer in ("se", "eca")       # the gate sits between the last conv and the shortcut add
-            last = dict(residual=None if gated else shortcut, act="" if gated else act, act_after_res=not gated)
+            gated = c.attn_layer in ("se", "eca")       # the gate sits between the last norm and the shortcut add
+            last = dict(residual=None if gated else shortcut, act="" if gated else act, act_after=not gated)
+            use_aa = bool(c.aa_layer) and stride == 2                                  # resnet.py:127,218
+            cstride = 1 if use_aa else stride
             if c.block == "basic_block":
-                y = b.conv(x, p + "/conv1/kernel", stride=stride, padding=1, bn=p + "/bn1", bn_eps=eps, act=act,
-                           cite="resnet.py:168-172")
-                y = b.conv(y, p + "/conv2/kernel", padding=1, bn=p + "/bn2", bn_eps=eps, cite="resnet.py:176-186", **last)
+                y = conv_norm(x, p + "/conv1/kernel", p + "/bn1", stride=cstride, padding=1, act=act,
+                              cite="resnet.py:168-172")
+                if use_aa:
+                    y = b.blur_pool(y, stride, cite="resnet.py:173-174")
+                y = conv_norm(y, p + "/conv2/kernel", p + "/bn2", padding=1, cite="resnet.py:176-186", **last)
             else:
-                y = b.conv(x, p + "/conv1/kernel", bn=p + "/bn1", bn_eps=eps, act=act, cite="resnet.py:269-271")
+                y = conv_norm(x, p + "/conv1/kernel", p + "/bn1", act=act, cite="resnet.py:269-271")
                 k2 = p + "/conv2/kernel"
+                kw2 = {}
                 if c.cardinality > 1:
                     # ResNeXt (resnet.py:229-236, Conv2D(groups=cardinality)): the grouped 3x3 runs as a dense
                     # convolution over the block-diagonal expansion of its kernel -- exact (the extra products are
-                    # x * 0), at cardinality x the multiply-accumulates; a grouped MFMA kernel is the next step
+                    # x * 0), at cardinality x the multiply-accumulates
                     k2 = b.define(k2 + ":dense", _expand_grouped_kernel(b.wget(k2), c.cardinality))
-                y = b.conv(y, k2, stride=stride, padding=1, bn=p + "/bn2", bn_eps=eps, act=act,
-                           flops_k=9 * y.C // c.cardinality if c.cardinality > 1 else None, cite="resnet.py:273-276")
-                y = b.conv(y, p + "/conv3/kernel", bn=p + "/bn3", bn_eps=eps, cite="resnet.py:280-290", **last)
+                    kw2["flops_k"] = 9 * y.C // c.cardinality
+                y = conv_norm(y, k2, p + "/bn2", stride=cstride, padding=1, act=act, cite="resnet.py:273-276", **kw2)
+                if use_aa:
+                    y = b.blur_pool(y, stride, cite="resnet.py:277-278")
+                y = conv_norm(y, p + "/conv3/kernel", p + "/bn3", cite="resnet.py:280-290", **last)
             if c.attn_layer == "eca":
-                # EcaModule (layers/attention.py:105-130): channel means -> Conv1D over the channel axis -> sigmoid.
-                # The Conv1D is a banded C x C matrix: one small GEMM (bf16 operands, fp32 gate) with existing kernels.
-                m = b.mean_rows(y, cite="layers/attention.py:122")
-                band = b.define(p + "/se/conv/kernel:band", _eca_band(b.wget(p + "/se/conv/kernel"), y.C))
-                g = b.dense(m, band, act="sigmoid", out_f32=True, cite="layers/attention.py:123-126")
+                # EcaModule (layers/attention.py:105-130): fp32 channel means -> Conv1D over the channel axis -> sigmoid
+                m = b.mean_rows(y, out_f32=True, cite="layers/attention.py:122")
+                g = b.eca_gate(m, p + "/se/conv/kernel", cite="layers/attention.py:123-126")
                 y = b.scale_channels(y, g, residual=shortcut, relu_after=True,
                                      cite="layers/attention.py:129 + resnet.py:289-290")
             if se:
@@ -301,19 +336,6 @@ def _expand_grouped_kernel(k: np.ndarray, groups: int) -> np.ndarray:
     for g in range(groups):
         dense[:, :, g * cg:(g + 1) * cg, g * og:(g + 1) * og] = k[:, :, :, g * og:(g + 1) * og]
     return dense
-
-
-def _eca_band(k: np.ndarray, channels: int) -> np.ndarray:
-    """Conv1D kernel (ks, 1, 1), zero padding (ks - 1) / 2 over the channel axis -> (C, C) matrix B with
-    gate_pre[o] = sum_i mean[i] * B[i][o], B[i][o] = k[i - o + pad] (layers/attention.py:110-125)."""
-    w = np.asarray(k, dtype=np.float32).reshape(-1)
-    pad = (w.shape[0] - 1) // 2
-    band = np.zeros((channels, channels), dtype=np.float32)
-    for j, v in enumerate(w):
-        d = j - pad                                   # input channel i = o + d
-        o = np.arange(max(0, -d), min(channels, channels - d))
-        band[o + d, o] = v
-    return band
 
 
 _D = dict(stem_width=32, stem_type="deep", downsample_mode="avg", first_conv="conv1/0")

@@ -145,7 +145,7 @@ class ViT(Model):
     def feature_names(self) -> List[str]:
         names = ["patch_embedding"]
         for j in range(self.cfg.nb_blocks):
-            names += [f"block_{j}"]
+            names += [f"block_{j}/attn", f"block_{j}"]        # vit.py:447-451
         return names + ["features_all", "features", "logits"]
 
     # -- lowering ------------------------------------------------------------------------------------
@@ -182,6 +182,9 @@ class ViT(Model):
             y = b.layernorm(x, p + "norm1", eps, cite="vit.py:222")
             qkv = b.dense(y, p + "attn/qkv/kernel", p + "attn/qkv/bias" if c.qkv_bias else None, cite="vit.py:155")
             a = b.attention(qkv, nh, scale, cite="vit.py:156-167", name=p + "attn")
+            if want_features:
+                # features["block_j/attn"]: the softmax map the fused kernel never writes (vit.py:160-163, 447-450)
+                b.p.mark_output(f"block_{j}/attn", b.attention_probs(qkv, nh, scale, cite="vit.py:160-163"))
             x = b.dense(a, p + "attn/proj/kernel", p + "attn/proj/bias", residual=x, cite="vit.py:169,228")
             y = b.layernorm(x, p + "norm2", eps, cite="vit.py:231")
             hdn = b.dense(y, p + "mlp/fc1/kernel", p + "mlp/fc1/bias", act=c.act_layer, cite="transformers.py:209-210")
@@ -223,6 +226,8 @@ class ViT(Model):
             return v.reshape(v.shape[0], 2, -1)
         if name in ("features", "logits"):
             return v.reshape(v.shape[0], -1)
+        if name.endswith("/attn"):
+            return v.reshape(v.shape[0], c.nb_heads, v.shape[-1], v.shape[-1])      # (B, H, N, N)
         return v
 
 

@@ -446,6 +446,15 @@ class Builder:
               flops=4 * nseq * heads * n * n * hd)
         return out
 
+    def attention_probs(self, qkv: TRef, heads: int, scale: float, cite="", name="") -> TRef:
+        """softmax(scale * Q K^T) as an fp32 (heads * N, N) tensor per image: the ``attn`` entry of the feature
+        dictionary (vit.py:160-163).  Only lowered when features are requested."""
+        d = qkv.C // 3
+        out = self.p.new_tensor(heads * qkv.rows, qkv.rows, dtype="f32", name=name or "attn_probs")
+        self.p.add("attention_probs", [qkv], out, cite=cite, heads=heads, hd=d // heads, scale=float(scale),
+                   n_tokens=qkv.rows)
+        return out
+
     def talking_heads_attention(self, qkv: TRef, heads: int, scale: float, prefix: str, cite="", name="") -> TRef:
         """CaiT TalkingHeadAttention between its qkv and proj layers (cait.py:236-256); ``prefix`` holds
         the proj_l / proj_w Dense(H -> H) layers."""
@@ -554,6 +563,46 @@ class Builder:
         self.p.add("scale_channels", ins, out, cite=cite, R=x.rows, C=x.C, has_residual=residual is not None,
                    act_after=1 if relu_after else 0)
         return out
+
+    def group_norm(self, x: TRef, prefix: str, groups: int, eps: float, *, act="", residual: Optional[TRef] = None,
+                   act_after="", cite="") -> TRef:
+        """GroupNormalization (layers/norm.py:37-165) + activation (+ shortcut add + activation)."""
+        p = self.p
+        g, b = self.wget(prefix + "/gamma"), self.wget(prefix + "/beta")
+        assert g.shape[0] == x.C and x.C % groups == 0, f"{prefix}: {x.C} channels, {groups} groups"
+        out = p.new_tensor(x.rows, x.C, x.H, x.W, name=prefix)
+        ws = p.new_tensor(1, 2 * groups, dtype="f32", name=prefix + ":stats")
+        consts = {"gamma": p.new_const(g, prefix + "/gamma"), "beta": p.new_const(b, prefix + "/beta")}
+        ins = [x] + ([residual] if residual is not None else [])
+        if residual is not None:
+            assert residual.rows == x.rows and residual.C == x.C
+        p.add("group_norm", ins, out, consts, cite=cite, extra_outputs=[ws], rows=x.rows, C=x.C, groups=groups,
+              eps=float(eps), act=act, act_after=act_after, has_residual=residual is not None, ws=ws.id)
+        return out
+
+    def blur_pool(self, x: TRef, stride: int, cite="") -> TRef:
+        """BlurPool2D(kernel_size=3, stride) (layers/blurpool.py:5-66)."""
+        pad = (3 + stride) // 2 - 1
+        OH, OW = (x.H + 2 * pad - 3) // stride + 1, (x.W + 2 * pad - 3) // stride + 1
+        out = self.p.new_tensor(OH * OW, x.C, OH, OW, name="blur_pool")
+        self.p.add("blur_pool", [x], out, cite=cite, H=x.H, W=x.W, C=x.C, stride=stride)
+        return out
+
+    def avg_pool(self, x: TRef, k: int, stride: int, cite="") -> TRef:
+        """AveragePooling2D(k, stride, "same"): border windows average their valid elements (resnet.py:299-301)."""
+        OH, OW = -(-x.H // stride), -(-x.W // stride)
+        out = self.p.new_tensor(OH * OW, x.C, OH, OW, name="avg_pool")
+        self.p.add("avg_pool", [x], out, cite=cite, H=x.H, W=x.W, C=x.C, k=k, stride=stride)
+        return out
+
+    def eca_gate(self, mean: TRef, kernel: str, gate_act="sigmoid", cite="") -> TRef:
+        """EcaModule gate from fp32 channel means (layers/attention.py:110-126)."""
+        assert mean.dtype == "f32" and mean.rows == 1
+        w = np.ascontiguousarray(self.wget(kernel).reshape(-1), dtype=np.float32)      # Conv1D kernel (k, 1, 1)
+        gate = self.p.new_tensor(1, mean.C, dtype="f32", name="eca_gate")
+        self.p.add("eca_gate", [mean], gate, {"w": self.p.new_const(w, kernel)}, cite=cite, C=mean.C, k=int(w.shape[0]),
+                   gate_act=gate_act)
+        return gate
 
     def patch_merge_ln(self, x: TRef, prefix: str, eps: float, cite="") -> TRef:
         p = self.p
@@ -764,6 +813,27 @@ class Plan:
                 self.calls.append((lib.tfimm_hip_scale_channels,
                                    (self.tptr(op.inputs[0]), self.tptr(op.inputs[1]), res, self.tptr(op.output), B,
                                     a["R"], a["C"], a["act_after"])))
+            elif k == "attention_probs":
+                self.calls.append((lib.tfimm_hip_attention_probs,
+                                   (self.tptr(op.inputs[0]), self.tptr(op.output), B, a["n_tokens"], a["heads"], a["hd"],
+                                    a["scale"])))
+            elif k == "group_norm":
+                res = self.tptr(op.inputs[1]) if a["has_residual"] else None
+                self.calls.append((lib.tfimm_hip_group_norm,
+                                   (self.tptr(op.inputs[0]), self.cptr(op.consts["gamma"]), self.cptr(op.consts["beta"]),
+                                    res, self.tptr(op.output), self.tptr(a["ws"]), B, a["rows"], a["C"], a["groups"],
+                                    a["eps"], ffi.ACT[a["act"]], ffi.ACT[a["act_after"]])))
+            elif k == "blur_pool":
+                self.calls.append((lib.tfimm_hip_blur_pool,
+                                   (self.tptr(op.inputs[0]), self.tptr(op.output), B, a["H"], a["W"], a["C"], a["stride"])))
+            elif k == "avg_pool":
+                self.calls.append((lib.tfimm_hip_avg_pool,
+                                   (self.tptr(op.inputs[0]), self.tptr(op.output), B, a["H"], a["W"], a["C"], a["k"],
+                                    a["stride"])))
+            elif k == "eca_gate":
+                self.calls.append((lib.tfimm_hip_eca_gate,
+                                   (self.tptr(op.inputs[0]), 1.0, self.cptr(op.consts["w"]), self.tptr(op.output), B,
+                                    a["C"], a["k"], ffi.ACT[a["gate_act"]])))
             elif k == "patch_merge_ln":
                 self.calls.append((lib.tfimm_hip_patch_merge_ln,
                                    (self.tptr(op.inputs[0]), self.tptr(op.output), self.cptr(op.consts["gamma"]),

@@ -141,3 +141,30 @@ if not is_model("vit_test_model"):
     def seresnet_test_model():
         return ResNet, ResNetConfig(name="seresnet_test_model", nb_classes=10, input_size=(32, 32), block="bottleneck",
                                     nb_blocks=(1, 1, 1, 1), nb_channels=(8, 16, 16, 32), attn_layer="se", se_ratio=0.25)
+
+    @register_model
+    def resnetd_odd_test_model():
+        """ResNet-D whose stage inputs are odd in W (50 -> 25 -> 13 -> 7 -> 4) and in H at stage 2 (58 -> 29 -> 15 -> 8):
+        the clipped border windows of AveragePooling2D(2, 2, "same") (resnet.py:299-301)."""
+        return ResNet, ResNetConfig(name="resnetd_odd_test_model", nb_classes=10, input_size=(58, 50), block="bottleneck",
+                                    nb_blocks=(1, 1, 1, 1), nb_channels=(8, 16, 24, 32), stem_width=8, stem_type="deep",
+                                    downsample_mode="avg", first_conv="conv1/0")
+
+    @register_model
+    def resnet_gn_test_model():
+        """GroupNormalization with its default 32 groups (what resnet50_gn uses): group sizes 2, 3, 4, 5, 8, ..."""
+        return ResNet, ResNetConfig(name="resnet_gn_test_model", nb_classes=10, input_size=(64, 64), block="bottleneck",
+                                    nb_blocks=(1, 1, 1, 1), nb_channels=(64, 96, 128, 160), norm_layer="group_norm")
+
+    @register_model
+    def resnetblur_test_model():
+        """BlurPool2D anti-aliasing in the stem pooling and in every stride-2 Bottleneck (what resnetblur50 uses)."""
+        return ResNet, ResNetConfig(name="resnetblur_test_model", nb_classes=10, input_size=(64, 64), block="bottleneck",
+                                    nb_blocks=(1, 2, 1, 1), nb_channels=(8, 16, 24, 32), aa_layer="blur_pool")
+
+    @register_model
+    def resnetblur_basic_test_model():
+        """BlurPool2D in BasicBlock (resnet.py:127-174), odd feature-map sizes (reflect padding at both borders)."""
+        return ResNet, ResNetConfig(name="resnetblur_basic_test_model", nb_classes=10, input_size=(60, 52),
+                                    block="basic_block", nb_blocks=(1, 1, 1, 1), nb_channels=(8, 16, 24, 32),
+                                    aa_layer="blur_pool")

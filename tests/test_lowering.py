@@ -44,11 +44,16 @@ def test_deep_stems_stay_unfused_and_avg_down_is_one_folded_conv(name):
         assert op.attrs["K"] == 4 * op.attrs["Cin"] and op.attrs["OH"] * 2 == op.attrs["H"]
 
 
-def test_avg_down_at_odd_sizes_is_refused():
+def test_avg_down_at_odd_sizes_pools_explicitly():
+    """odd feature maps: AveragePooling2D(2, 2, 'same') clips its last window (resnet.py:299-301), so the shortcut is
+    tfimm_hip_avg_pool + the 1x1 convolution instead of the folded 2x2 one; convnets accept any input size"""
     m = tfimm.create_model("resnet26d")
     m.set_weights(synthetic_weights(m))
-    with pytest.raises(NotImplementedError, match="odd"):
-        m.program(200, 200)              # 200 -> stem 100 -> pool 50 -> 25 (odd) at the next transition
+    prog = m.program(200, 200)           # 200 -> stem 100 -> pool 50 -> 25 (odd) -> 13 (odd) -> 7
+    pools = [op for op in prog.ops if op.kind == "avg_pool"]
+    assert [(op.attrs["H"], prog.tensors[op.output].H) for op in pools] == [(25, 13), (13, 7)]
+    folded = [op for op in prog.ops if op.kind == "gemm" and op.attrs.get("KH") == 2 and op.attrs.get("stride") == 2]
+    assert len(folded) == 1 and folded[0].attrs["H"] == 50
 
 
 def test_environment_switch_keeps_the_two_op_path(monkeypatch):
@@ -104,13 +109,22 @@ def test_resnext_and_eca_lower_to_existing_ops_and_the_oracle_runs_them():
         assert y.shape == (2, 10) and np.isfinite(y).all()
 
 
-def test_which_registered_resnets_are_still_refused():
-    """of the reference's registered ResNet-module configurations only the GroupNorm and the BlurPool one are not
-    built (checked on the configurations: building all ~70 programs would take minutes)"""
-    refused = []
+def test_every_registered_resnet_is_supported():
+    """all configurations the reference registers in its ResNet module lower (checked on the configurations:
+    building all ~70 programs would take minutes)"""
     for name in tfimm.list_models(module="resnet"):
-        try:
-            tfimm.create_model(name).check_supported()
-        except NotImplementedError:
-            refused.append(name)
-    assert sorted(refused) == ["resnet50_gn", "resnetblur50"], refused
+        tfimm.create_model(name).check_supported()
+
+
+def test_group_norm_and_blur_pool_lowering():
+    kinds, prog = _kinds("resnet_gn_test_model")
+    # every convolution is followed by its own GroupNorm kernel; nothing is folded, the stem is not fused
+    assert "stem_pool" not in kinds and kinds.count("group_norm") == 1 + 4 * 3 + 4
+    last = [op for op in prog.ops if op.kind == "group_norm" and op.attrs["has_residual"]]
+    assert len(last) == 4 and all(op.attrs["act_after"] == "relu" and op.attrs["act"] == "" for op in last)
+    kinds, prog = _kinds("resnetblur_test_model")
+    blurs = [op for op in prog.ops if op.kind == "blur_pool"]
+    assert len(blurs) == 1 + 3 and "stem_pool" not in kinds
+    assert [op.attrs["stride"] for op in prog.ops if op.kind == "maxpool"] == [1]         # resnet.py:534
+    strided = [op for op in prog.ops if op.kind == "gemm" and op.attrs.get("KH") == 3 and op.attrs.get("stride") == 2]
+    assert not strided                     # the blur layer takes care of the stride (resnet.py:132, 233)
