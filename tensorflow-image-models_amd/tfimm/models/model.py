@@ -127,6 +127,11 @@ class Model:
         return [f"{self.name}/{k}:0" if with_prefix else k for k in self._specs]
 
     def set_weights(self, new: Dict[str, np.ndarray], strict: bool = True):
+        """Replace weights by name.  ``strict`` (default): every variable of the model must be provided and no unknown
+        name may appear (the build-time constants of ``keys_to_ignore_on_load`` excepted) -- a truncated or mismatched
+        checkpoint fails loudly instead of leaving initialised values in place.  All names and shapes are validated
+        before anything is committed, so a failed call leaves the model untouched."""
+        staged: Dict[str, np.ndarray] = {}
         for k, v in new.items():
             if k.startswith(self.name + "/"):
                 k = k[len(self.name) + 1:]
@@ -141,11 +146,12 @@ class Model:
             v = np.asarray(v, dtype=np.float32)
             if tuple(v.shape) != tuple(self._specs[k].shape):
                 raise ValueError(f"{self.name}: weight '{k}' has shape {v.shape}, expected {self._specs[k].shape}")
-            self._weights[k] = v
+            staged[k] = v
         if strict:
-            missing = [k for k in self._specs if k not in self._weights]
+            missing = [k for k in self._specs if k not in staged]
             if missing:
-                raise KeyError(f"{self.name}: missing weights {missing[:5]}...")
+                raise KeyError(f"{self.name}: {len(missing)} weights missing from the provided set, e.g. {missing[:5]}")
+        self._weights.update(staged)
         self._programs.clear()
         self._plans.clear()
         self._captured.clear()

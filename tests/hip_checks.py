@@ -752,6 +752,103 @@ CASES["patch_merge_ln_c1024"] = lambda: _patch_merge_case(1, 2, 2, 1024, 101)   
 CASES["patch_merge_ln_c12_scalar"] = lambda: _patch_merge_case(2, 4, 4, 12, 102)  # C % 8 != 0: element-wise kernel
 
 
+# ---------------------------------------------------------------------------------------------
+# feature-path / ResNet-variant kernels (csrc/features.hip)
+# ---------------------------------------------------------------------------------------------
+def _attn_probs_case(B, n, heads, hd, seed):
+    import hip_ops as H
+    r = _rng(seed)
+    D = heads * hd
+    qkv = _bf(r.standard_normal((B, n, 3 * D)))
+    scale = hd ** -0.5
+    t = torch.from_numpy(qkv).reshape(B, n, 3, heads, hd).permute(2, 0, 3, 1, 4).double()     # vit.py:156-158
+    ref = torch.softmax(scale * (t[0] @ t[1].transpose(-1, -2)), -1).numpy()
+    got = H.attention_probs(H.dev_bf16(qkv), B, n, heads, hd, scale)
+    H.sync()
+    return _err(_cpu(got), ref), TOL_F32
+
+
+CASES["attn_probs_vit_197_h3_hd64"] = lambda: _attn_probs_case(2, 197, 3, 64, 160)
+CASES["attn_probs_hd2_n17"] = lambda: _attn_probs_case(3, 17, 2, 2, 161)          # the reference's mini: scalar loads
+CASES["attn_probs_n577_hd48"] = lambda: _attn_probs_case(1, 577, 2, 48, 162)      # 10 keys per lane
+
+
+def _group_norm_case(B, Hh, Ww, Cc, groups, seed, act="", residual=False):
+    import hip_ops as H
+    r = _rng(seed)
+    x = _bf(r.standard_normal((B, Hh, Ww, Cc)) * r.uniform(0.5, 2.0, Cc) + r.standard_normal(Cc))
+    g = r.uniform(0.5, 1.5, Cc).astype(np.float32)
+    b = r.standard_normal(Cc).astype(np.float32)
+    res = _bf(r.standard_normal((B, Hh, Ww, Cc))) if residual else None
+    ref = O.group_norm(torch.from_numpy(x), torch.from_numpy(g), torch.from_numpy(b), groups, 1e-5)
+    if residual:
+        ref = O.activation(ref + torch.from_numpy(res), act)
+    else:
+        ref = O.activation(ref, act)
+    got = H.group_norm(H.dev_bf16(x.reshape(B, Hh * Ww, Cc)), H.dev_f32(g), H.dev_f32(b), groups, 1e-5,
+                       act="" if residual else act, residual=None if res is None else H.dev_bf16(res.reshape(B, -1, Cc)),
+                       act_after=act if residual else "")
+    H.sync()
+    return _err(_cpu(got).reshape(ref.shape), ref.numpy()), TOL_BF16
+
+
+CASES["group_norm_c64_g32_56x56_relu"] = lambda: _group_norm_case(3, 56, 56, 64, 32, 163, act="relu")     # group size 2
+CASES["group_norm_c256_g32_res_relu"] = lambda: _group_norm_case(2, 14, 14, 256, 32, 164, act="relu", residual=True)
+CASES["group_norm_c2048_g32_7x7"] = lambda: _group_norm_case(2, 7, 7, 2048, 32, 165)                      # one row per pass
+CASES["group_norm_c96_g32"] = lambda: _group_norm_case(2, 9, 5, 96, 32, 166, act="relu")                  # group size 3: a vector spans groups
+CASES["group_norm_c12_g3_scalar"] = lambda: _group_norm_case(2, 5, 7, 12, 3, 167)                         # C % 8 != 0
+CASES["group_norm_c2560_two_vector_blocks"] = lambda: _group_norm_case(1, 3, 3, 2560, 32, 168)            # 320 channel vectors > 256 threads
+
+
+def _blur_case(B, Hh, Ww, Cc, stride, seed):
+    import hip_ops as H
+    r = _rng(seed)
+    x = _bf(r.standard_normal((B, Hh, Ww, Cc)))
+    ref = O.blur_pool2d(torch.from_numpy(x), stride).numpy()
+    got = H.blur_pool(H.dev_bf16(x), stride)
+    H.sync()
+    return _err(_cpu(got), ref), TOL_BF16
+
+
+CASES["blur_pool_s2_even_c64"] = lambda: _blur_case(2, 16, 12, 64, 2, 169)
+CASES["blur_pool_s2_odd_c24"] = lambda: _blur_case(2, 15, 13, 24, 2, 170)        # reflect at both borders
+CASES["blur_pool_s2_c10_scalar"] = lambda: _blur_case(2, 6, 7, 10, 2, 171)
+CASES["blur_pool_s1_c8"] = lambda: _blur_case(1, 5, 5, 8, 1, 172)
+
+
+def _avg_pool_case(B, Hh, Ww, Cc, k, stride, seed):
+    import hip_ops as H
+    r = _rng(seed)
+    x = _bf(r.standard_normal((B, Hh, Ww, Cc)))
+    ref = O.avg_pool2d_same(torch.from_numpy(x), k, stride).numpy()
+    got = H.avg_pool(H.dev_bf16(x), k, stride)
+    H.sync()
+    return _err(_cpu(got), ref), TOL_BF16
+
+
+CASES["avg_pool_2x2_s2_odd_15x13_c32"] = lambda: _avg_pool_case(2, 15, 13, 32, 2, 2, 173)    # clipped last row and column
+CASES["avg_pool_2x2_s2_even_c64"] = lambda: _avg_pool_case(2, 8, 6, 64, 2, 2, 174)
+CASES["avg_pool_3x3_s2_c12_scalar"] = lambda: _avg_pool_case(2, 7, 9, 12, 3, 2, 175)          # padding on both sides
+
+
+def _eca_case(B, Cc, k, seed):
+    import hip_ops as H
+    r = _rng(seed)
+    mean = r.standard_normal((B, Cc)).astype(np.float32)
+    w = r.standard_normal(k).astype(np.float32)
+    pad = (k - 1) // 2
+    t = torch.nn.functional.conv1d(torch.nn.functional.pad(torch.from_numpy(mean)[:, None, :], (pad, pad)),
+                                   torch.from_numpy(w).reshape(1, 1, -1))[:, 0, :]          # layers/attention.py:123-125
+    ref = torch.sigmoid(t).numpy()
+    got = H.eca_gate(H.dev_f32(mean * 49), 1.0 / 49, H.dev_f32(w))
+    H.sync()
+    return _err(_cpu(got), ref), TOL_F32
+
+
+CASES["eca_gate_c2048_k7"] = lambda: _eca_case(3, 2048, 7, 176)
+CASES["eca_gate_c32_k3"] = lambda: _eca_case(2, 32, 3, 177)
+
+
 def run_case(name):
     out = CASES[name]()
     err, tol = out

@@ -237,3 +237,42 @@ def patch_merge_ln(x, gamma, beta, H, W, eps):
     ffi.check(lib.tfimm_hip_patch_merge_ln(ptr(x), ptr(out), ptr(gamma), ptr(beta), B, H, W, Cc, float(eps),
                                            stream()), "patch_merge_ln")
     return out
+
+
+def attention_probs(qkv, B, n, heads, hd, scale):
+    out = torch.empty(B, heads, n, n, dtype=torch.float32, device=DEV)
+    ffi.check(lib.tfimm_hip_attention_probs(ptr(qkv), ptr(out), B, n, heads, hd, float(scale), stream()), "attention_probs")
+    return out
+
+
+def group_norm(x, gamma, beta, groups, eps, act="", residual=None, act_after=""):
+    B, R, Cc = x.shape
+    out = torch.empty_like(x)
+    ws = torch.full((B, groups, 2), 7.0, dtype=torch.float32, device=DEV)     # poisoned: the entry point zeroes it
+    ffi.check(lib.tfimm_hip_group_norm(ptr(x), ptr(gamma), ptr(beta), ptr(residual), ptr(out), ptr(ws), B, R, Cc, groups,
+                                       float(eps), ffi.ACT[act], ffi.ACT[act_after], stream()), "group_norm")
+    return out
+
+
+def blur_pool(x, stride):
+    B, H, W, Cc = x.shape
+    p = (3 + stride) // 2 - 1
+    OH, OW = (H + 2 * p - 3) // stride + 1, (W + 2 * p - 3) // stride + 1
+    out = torch.empty(B, OH, OW, Cc, dtype=torch.bfloat16, device=DEV)
+    ffi.check(lib.tfimm_hip_blur_pool(ptr(x), ptr(out), B, H, W, Cc, stride, stream()), "blur_pool")
+    return out
+
+
+def avg_pool(x, k, stride):
+    B, H, W, Cc = x.shape
+    out = torch.empty(B, -(-H // stride), -(-W // stride), Cc, dtype=torch.bfloat16, device=DEV)
+    ffi.check(lib.tfimm_hip_avg_pool(ptr(x), ptr(out), B, H, W, Cc, k, stride, stream()), "avg_pool")
+    return out
+
+
+def eca_gate(sums, inv_count, w, gate_act="sigmoid"):
+    B, Cc = sums.shape
+    gate = torch.empty(B, Cc, dtype=torch.float32, device=DEV)
+    ffi.check(lib.tfimm_hip_eca_gate(ptr(sums), float(inv_count), ptr(w), ptr(gate), B, Cc, int(w.shape[0]),
+                                     ffi.ACT[gate_act], stream()), "eca_gate")
+    return gate

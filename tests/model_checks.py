@@ -45,10 +45,18 @@ def compare_model(name, batch=2, seed=2021, size=None, features=False, **overrid
     out = {}
     if features:
         (ref, ref_f), (got, got_f) = ref, got
+        assert list(got_f.keys()) == list(ref_f.keys()), (list(got_f.keys()), list(ref_f.keys()))
         for k in got_f:
             out["feat:" + k] = rel_err(got_f[k].numpy().reshape(ref_f[k].shape), ref_f[k])
     g = got.numpy()
     out["logits"] = rel_err(g.reshape(ref.shape), ref)
-    out["top1_agree"] = float((g.reshape(ref.shape).argmax(-1) == ref.argmax(-1)).mean())
+    gf, rf = g.reshape(-1, ref.shape[-1]), ref.reshape(-1, ref.shape[-1])
+    out["top1_agree"] = float((gf.argmax(-1) == rf.argmax(-1)).mean())
+    # random-init weights give near-Gaussian logits whose top-1 / top-2 gap is often inside the bf16 error band: an argmax
+    # that differs only where the ORACLE's own margin is below twice the observed error is not a disagreement
+    srt = np.sort(rf, -1)
+    margin = srt[:, -1] - srt[:, -2]
+    max_abs = float(np.abs(gf - rf).max())
+    out["top1_agree_outside_error_band"] = float(((gf.argmax(-1) == rf.argmax(-1)) | (margin < 2 * max_abs)).mean())
     out["shape"] = g.shape
     return out

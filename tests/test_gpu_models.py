@@ -11,12 +11,13 @@ MINIS = ["vit_test_model", "deit_test_model", "vit_hd64_test_model", "resnet_tes
          "resnet50_mini_test_model", "seresnet_test_model", "swin_test_model", "swin_shift_test_model",
          "efficientnet_test_model", "efficientnet_same_test_model", "convnext_odd_test_model", "convnext_wide_test_model",
          "cait_hd48_test_model", "cait_hd32_test_model", "resnetd_test_model", "resnext_test_model",
-         "ecaresnet_test_model"]
+         "ecaresnet_test_model", "resnetd_odd_test_model", "resnet_gn_test_model", "resnetblur_test_model",
+         "resnetblur_basic_test_model"]
 FULL = [("vit_tiny_patch16_224", 2), ("deit_tiny_distilled_patch16_224", 2), ("resnet18", 2), ("resnet50", 2),
         ("vit_base_patch16_224", 1), ("swin_tiny_patch4_window7_224", 2), ("efficientnet_b0", 2),
         ("swin_base_patch4_window7_224", 1), ("efficientnet_b4", 1), ("efficientnet_v2_b0", 2), ("mobilenet_v2_100", 2), ("convnext_tiny", 2),
         ("convnext_base_384_in22ft1k", 1), ("cait_xxs24_224", 2), ("cait_s24_224", 1), ("cait_m36_384", 1), ("resnet50d", 2),
-        ("seresnet152d", 1), ("resnext50_32x4d", 1), ("ecaresnet50d", 1)]
+        ("seresnet152d", 1), ("resnext50_32x4d", 1), ("ecaresnet50d", 1), ("resnet50_gn", 1), ("resnetblur50", 1)]
 
 
 @pytest.mark.parametrize("name", MINIS)
@@ -42,6 +43,31 @@ def test_resnet_other_input_size():
     """convnets accept any spatial size at inference."""
     r = mc.compare_model("resnet18", batch=2, size=(160, 128))
     assert r["logits"] <= mc.TOL_LOGITS, r
+
+
+def test_resnet_d_at_an_odd_input_size():
+    """ResNet-D shortcuts at odd feature-map sizes (resnet.py:299-301): 250 -> 125 -> 63 -> 32 -> 16 -> 8."""
+    r = mc.compare_model("resnet26d", batch=2, size=(250, 250))
+    assert r["logits"] <= mc.TOL_LOGITS and r["top1_agree_outside_error_band"] == 1.0, r
+
+
+@pytest.mark.parametrize("name", ["resnet50_mini_test_model", "seresnet_test_model", "swin_shift_test_model",
+                                  "efficientnet_same_test_model", "resnet_gn_test_model", "resnetblur_test_model"])
+def test_features_of_every_family(name):
+    """return_features=True against the oracle for the families whose features had no GPU comparison
+    (resnet.py:562-584, swin.py:467-517, efficientnet.py:270-345)."""
+    r = mc.compare_model(name, batch=2, features=True)
+    feats = [k for k in r if k.startswith("feat:")]
+    assert len(feats) >= 4
+    bad = {k: v for k, v in r.items() if (k.startswith("feat:") or k == "logits") and v > mc.TOL_LOGITS}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("name,batch", [("resnet50", 2), ("swin_tiny_patch4_window7_224", 1), ("efficientnet_b0", 2)])
+def test_features_full_size(name, batch):
+    r = mc.compare_model(name, batch=batch, features=True)
+    bad = {k: v for k, v in r.items() if (k.startswith("feat:") or k == "logits") and v > mc.TOL_LOGITS}
+    assert not bad, bad
 
 
 def test_convnext_other_input_size_and_features():

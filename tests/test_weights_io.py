@@ -148,3 +148,30 @@ def test_interpolate_input_oracle_and_lowering():
         strict.set_weights(w)
         with pytest.raises(ValueError, match="interpolate_input"):
             strict.program(*sz)
+
+
+def test_strict_loading_reports_missing_and_leaves_the_model_untouched(tmp_path):
+    """a truncated checkpoint must fail loudly (the reference's Keras loader does); a mis-shaped one must not leave
+    the model half-updated"""
+    import pytest
+    import test_architectures  # noqa: F401
+    import tfimm
+    from tfimm.utils.init import synthetic_weights
+    m = tfimm.create_model("resnet_test_model_1")
+    w = synthetic_weights(m, 3)
+    m.set_weights(w)
+    before = {k: v.copy() for k, v in m.weights.items()}
+    dropped = next(iter(w))
+    partial = {k: v for k, v in w.items() if k != dropped}
+    with pytest.raises(KeyError, match="missing"):
+        m.set_weights(partial)
+    np.savez(tmp_path / "partial.npz", **partial)
+    with pytest.raises(KeyError, match="missing"):
+        m.load_weights(str(tmp_path / "partial.npz"))
+    m.set_weights(partial, strict=False)                 # explicit opt-out still works
+    bad = dict(synthetic_weights(m, 4))
+    last = list(bad)[-1]
+    bad[last] = np.zeros((3, 3), np.float32)
+    with pytest.raises(ValueError, match="shape"):
+        m.set_weights(bad)
+    assert all(np.array_equal(m.weights[k], before[k]) for k in before)      # nothing of `bad` was committed
