@@ -324,6 +324,36 @@ TFIMM_API int tfimm_hip_patch_merge_ln(const void* x, void* y, const float* gamm
                              int B, int H, int W, int C, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * tfimm_hip_conv_chain: the tail of a ResNet bottleneck block in ONE launch,
+ *     mid = act1( conv_{KH x KW, stride, pad}(x) * W1 + b1 )            [M][C1]   never written to memory
+ *     out = act2( mid . W2^T + b2 + residual )                          [M][N2]
+ * i.e. pad2 / conv2 / bn2 / act2 / conv3 / bn3 / += shortcut / act3 of Bottleneck.call (resnet.py:273-290), BatchNorm
+ * folded into (W, b) by the host.  x: bf16 NHWC [B][H][W][Cin], Cin % 64 == 0; w1: bf16 [C1][ldw1 = KH*KW*Cin] in
+ * (ky, kx, ci) order; w2: bf16 [N2][ldw2] with its K (= C1) axis PERMUTED: within every 16 channels the two middle
+ * quads are swapped (k-slot 16t + s holds channel 16t + {0..3, 8..11, 4..7, 12..15}[s]) -- the order in which a wave's
+ * GEMM-1 accumulators become the register operand of GEMM 2 (tfimm/engine/pack.py chain_k_order); residual (may be
+ * NULL) / out: bf16 rows of ldr / ldc elements (multiples of 8); M = B*OH*OW.  Built for the ResNet stage-1 shape --
+ * 3x3 / stride 1 / pad 1, Cin = C1 = 64, W <= 63, N2 in {256, 512}; anything else returns TFIMM_EUNSUP and the caller
+ * runs the two convolutions as two tfimm_hip_gemm launches (same arithmetic: fp32 accumulation, the intermediate
+ * rounded to bf16 once; only the summation order inside GEMM 2's 16-wide k-steps differs).
+ * ------------------------------------------------------------------------------------- */
+typedef struct tfimm_chain_desc {
+  const void* x;
+  const void* w1;
+  const float* b1;
+  const void* w2;
+  const float* b2;
+  const void* residual;
+  void* out;
+  int32_t B, H, W, Cin, KH, KW, stride, pad_t, pad_l, OH, OW;
+  int32_t C1, N2;
+  int32_t ldw1, ldw2, ldr, ldc;
+  int32_t act1, act2;       /* TFIMM_ACT_*; act2 is applied after the residual add */
+} tfimm_chain_desc;
+
+TFIMM_API int tfimm_hip_conv_chain(const tfimm_chain_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * tfimm_hip_attention_probs: probs[b][h][i][j] = softmax_j(scale * q[b,i,h,:] . k[b,j,h,:]) in fp32 --
  * the attention map ViTMultiHeadAttention.call returns as features["attn"] when return_features=True
  * (vit.py:160-163; ViT.forward_features stores it as "block_<j>/attn", vit.py:447-450).  qkv: bf16

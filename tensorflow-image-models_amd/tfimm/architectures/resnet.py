@@ -295,10 +295,19 @@ class ResNet(Model):
                     # x * 0), at cardinality x the multiply-accumulates
                     k2 = b.define(k2 + ":dense", _expand_grouped_kernel(b.wget(k2), c.cardinality))
                     kw2["flops_k"] = 9 * y.C // c.cardinality
-                y = conv_norm(y, k2, p + "/bn2", stride=cstride, padding=1, act=act, cite="resnet.py:273-276", **kw2)
-                if use_aa:
-                    y = b.blur_pool(y, stride, cite="resnet.py:277-278")
-                y = conv_norm(y, p + "/conv3/kernel", p + "/bn3", cite="resnet.py:280-290", **last)
+                fused = None
+                if not gn and not gated and not use_aa and c.cardinality == 1 and act == "relu":
+                    # conv2 + bn2 + act2 + conv3 + bn3 + shortcut add + act3 as one launch: the `width`-channel
+                    # intermediate stays in LDS (stages 1 and 2; None for shapes that kernel is not built for)
+                    fused = b.conv_chain(y, k2, p + "/bn2", p + "/conv3/kernel", p + "/bn3", stride=cstride, padding=1,
+                                         bn_eps=eps, act1=act, act2=act, residual=shortcut, cite="resnet.py:273-290")
+                if fused is not None:
+                    y = fused
+                else:
+                    y = conv_norm(y, k2, p + "/bn2", stride=cstride, padding=1, act=act, cite="resnet.py:273-276", **kw2)
+                    if use_aa:
+                        y = b.blur_pool(y, stride, cite="resnet.py:277-278")
+                    y = conv_norm(y, p + "/conv3/kernel", p + "/bn3", cite="resnet.py:280-290", **last)
             if c.attn_layer == "eca":
                 # EcaModule (layers/attention.py:105-130): fp32 channel means -> Conv1D over the channel axis -> sigmoid
                 m = b.mean_rows(y, out_f32=True, cite="layers/attention.py:122")

@@ -104,7 +104,7 @@ class Program:
             a = op.attrs
             if op.kind in ("gemm", "stem_pool"):
                 total += 2 * a["M"] * a["N"] * a["K_true"]
-            elif op.kind in ("attention", "talking_heads_attention"):
+            elif op.kind in ("attention", "talking_heads_attention", "conv_chain"):
                 total += a["flops"]
             elif op.kind == "dwconv":
                 total += 2 * a["OH"] * a["OW"] * a["C"] * a["k"] * a["k"]
@@ -321,6 +321,39 @@ class Builder:
         p.add("gemm", ins, out, consts, cite=cite, **attrs)
         if then_maxpool is not None:
             return self.maxpool(out, *then_maxpool, cite=cite)
+        return out
+
+    def conv_chain(self, x: TRef, kernel1: str, bn1: str, kernel2: str, bn2: str, *, stride=1, padding=1, bn_eps=1e-5,
+                   act1="relu", act2="relu", residual: Optional[TRef] = None, cite="") -> Optional[TRef]:
+        """k x k Conv2D + BN + act1 followed by a 1x1 Conv2D + BN (+ residual) + act2 as ONE launch
+        (tfimm_hip_conv_chain): the tail of a ResNet bottleneck block with the intermediate kept in LDS.  Returns None
+        when the shape is outside what that kernel is built for (the caller then lowers the two convolutions)."""
+        p = self.p
+        k1, k2 = self.wget(kernel1), self.wget(kernel2)
+        kh, kw, cin, c1 = k1.shape
+        n2 = k2.shape[3]
+        # what tfimm_hip_conv_chain is built for: 3x3 / stride 1 / pad 1 over 64 -> 64 channels, rows of at most 63 pixels
+        if (x.C != cin or (kh, kw, cin, c1) != (3, 3, 64, 64) or stride != 1 or int(padding) != 1 or x.W > 63
+                or n2 not in (256, 512) or k2.shape[:3] != (1, 1, c1) or os.environ.get("TFIMM_NO_CHAIN", "0") == "1"):
+            return None
+        pad = int(padding)
+        OH = (x.H + 2 * pad - kh) // stride + 1
+        OW = (x.W + 2 * pad - kw) // stride + 1
+        s1, t1 = self.bn(bn1, bn_eps)
+        s2, t2 = self.bn(bn2, bn_eps)
+        wt1, b1, kk, mode = pack.pack_conv(k1, s1, t1, x.C)
+        assert mode == 1 and kk == kh * kw * cin and wt1.shape[1] == kk
+        # GEMM 2 reads its A operand straight from GEMM 1's accumulator registers: W2's K axis goes in that order
+        wt2, b2 = pack.pack_dense((k2.reshape(c1, n2) * s2.reshape(1, n2))[pack.chain_k_order(c1)], t2)
+        out = p.new_tensor(OH * OW, n2, OH, OW, name=kernel2)
+        consts = {"w1": p.new_const(wt1, kernel1), "b1": p.new_const(b1, kernel1 + ":bias"),
+                  "w2": p.new_const(wt2, kernel2), "b2": p.new_const(b2, kernel2 + ":bias")}
+        ins = [x] + ([residual] if residual is not None else [])
+        if residual is not None:
+            assert residual.rows == OH * OW and residual.C == n2
+        p.add("conv_chain", ins, out, consts, cite=cite, H=x.H, W=x.W, Cin=cin, KH=kh, KW=kw, stride=stride, pad=pad,
+              OH=OH, OW=OW, C1=c1, N2=n2, ldw1=wt1.shape[1], ldw2=wt2.shape[1], act1=act1, act2=act2,
+              has_residual=residual is not None, flops=2 * OH * OW * (c1 * kh * kw * cin + n2 * c1))
         return out
 
     def dense(self, x: TRef, kernel: str, bias: Optional[str] = None, *, act="",
@@ -732,6 +765,19 @@ class Plan:
                 self._gemm_descs.append(d)
                 self._gemm_call_index.append(len(self.calls))
                 self.calls.append((lib.tfimm_hip_gemm, (C.byref(d),)))
+            elif k == "conv_chain":
+                d = ffi.ChainDesc()
+                d.x = self.tptr(op.inputs[0])
+                d.w1, d.b1 = self.cptr(op.consts["w1"]), self.cptr(op.consts["b1"])
+                d.w2, d.b2 = self.cptr(op.consts["w2"]), self.cptr(op.consts["b2"])
+                d.residual = self.tptr(op.inputs[1]) if a["has_residual"] else None
+                d.out = self.tptr(op.output)
+                d.B, d.H, d.W, d.Cin, d.KH, d.KW = B, a["H"], a["W"], a["Cin"], a["KH"], a["KW"]
+                d.stride, d.pad_t, d.pad_l, d.OH, d.OW = a["stride"], a["pad"], a["pad"], a["OH"], a["OW"]
+                d.C1, d.N2, d.ldw1, d.ldw2, d.ldr, d.ldc = a["C1"], a["N2"], a["ldw1"], a["ldw2"], a["N2"], a["N2"]
+                d.act1, d.act2 = ffi.ACT[a["act1"]], ffi.ACT[a["act2"]]
+                self._keepalive.append(d)
+                self.calls.append((lib.tfimm_hip_conv_chain, (C.byref(d),)))
             elif k == "layernorm":
                 xp = self.tptr(op.inputs[0]) + a["x_byte_offset"]
                 self.calls.append((lib.tfimm_hip_layernorm,

@@ -120,3 +120,12 @@ def swin_bias_tiles(rel_bias: np.ndarray, window: int, shift: int) -> np.ndarray
         mask = np.where(reg[:, None] != reg[None, :], -100.0, 0.0) if shift > 0 else 0.0
         out[kind, :, :, :n] = (rel_bias.astype(np.float64) + mask) * log2e
     return out
+
+
+def chain_k_order(c1: int) -> np.ndarray:
+    """K-axis order of the second GEMM of tfimm_hip_conv_chain: position 16 t + s holds channel
+    16 t + (0..3, 8..11, 4..7, 12..15)[s] -- the order in which a wave's GEMM-1 accumulators (one pixel per lane, channel
+    quads 8 q + 4 (lane >> 5)) line up as the 8-consecutive-k register operand of v_mfma_f32_32x32x16_bf16."""
+    assert c1 % 16 == 0
+    inner = np.array([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
+    return (np.arange(0, c1, 16)[:, None] + inner[None, :]).reshape(-1)

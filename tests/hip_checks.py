@@ -849,6 +849,46 @@ CASES["eca_gate_c2048_k7"] = lambda: _eca_case(3, 2048, 7, 176)
 CASES["eca_gate_c32_k3"] = lambda: _eca_case(2, 32, 3, 177)
 
 
+# ---------------------------------------------------------------------------------------------
+# fused bottleneck tail (csrc/gemm_chain_kernel.h): 3x3 conv + BN + relu -> 1x1 conv + BN + residual + relu
+# ---------------------------------------------------------------------------------------------
+def _chain_case(B, Hh, Ww, C1, N2, stride, seed, residual=True):
+    import hip_ops as H
+    r = _rng(seed)
+    cin = C1
+    x = _bf(r.standard_normal((B, Hh, Ww, cin)))
+    k1 = (r.standard_normal((3, 3, cin, C1)) / math.sqrt(9 * cin)).astype(np.float32)
+    s1, t1 = r.uniform(0.5, 1.5, C1).astype(np.float32), r.standard_normal(C1).astype(np.float32)
+    k2 = (r.standard_normal((1, 1, C1, N2)) / math.sqrt(C1)).astype(np.float32)
+    s2, t2 = r.uniform(0.5, 1.5, N2).astype(np.float32), r.standard_normal(N2).astype(np.float32)
+    wt1, b1, K1, mode = pack.pack_conv(k1, s1, t1, cin)
+    wt2, b2 = pack.pack_dense((k2.reshape(C1, N2) * s2.reshape(1, N2))[pack.chain_k_order(C1)], t2)
+    # reference: the two-launch path's arithmetic -- folded weights rounded to bf16, intermediate rounded to bf16 once
+    mid = O.conv2d(O.zero_pad2d(torch.from_numpy(x), 1), torch.from_numpy(_bf(k1 * s1.reshape(1, 1, 1, -1))), None, stride=stride)
+    mid = torch.from_numpy(_bf(torch.relu(mid + torch.from_numpy(t1)).numpy()))
+    OH, OW = mid.shape[1], mid.shape[2]
+    y = O.conv2d(mid, torch.from_numpy(_bf(k2 * s2.reshape(1, 1, 1, -1)))) + torch.from_numpy(t2)
+    res = _bf(r.standard_normal((B, OH, OW, N2))) if residual else None
+    if residual:
+        y = y + torch.from_numpy(res)
+    y = torch.relu(y).numpy()
+    got = H.conv_chain(H.dev_bf16(x), H.dev_bits(wt1), H.dev_f32(b1), H.dev_bits(wt2), H.dev_f32(b2),
+                       None if res is None else H.dev_bf16(res.reshape(-1, N2)), KH=3, KW=3, stride=stride, pad=1,
+                       OH=OH, OW=OW, C1=C1, N2=N2)
+    H.sync()
+    return _err(_cpu(got).reshape(B, OH, OW, N2), y), TOL_BF16
+
+
+CASES["chain_56x56_b3"] = lambda: _chain_case(3, 56, 56, 64, 256, 1, 180)                      # ResNet-50 stage 1: 37 tiles, ragged last
+CASES["chain_odd_57x41"] = lambda: _chain_case(2, 57, 41, 64, 256, 1, 181)                     # odd sizes: every border case of the tap mask
+CASES["chain_no_residual_tiny"] = lambda: _chain_case(1, 5, 7, 64, 256, 1, 182, residual=False)   # one partial tile, strip mostly out of range
+CASES["chain_63_wide"] = lambda: _chain_case(2, 9, 63, 64, 256, 1, 183)                        # the widest row the strip holds
+CASES["chain_multiround_b40"] = lambda: _chain_case(40, 56, 56, 64, 256, 1, 185)               # 490 tiles: two per workgroup
+CASES["chain_multiround_b130_28x28"] = lambda: _chain_case(130, 28, 28, 64, 256, 1, 186)       # 399 tiles, images smaller than a tile... of 256 pixels
+CASES["chain_n512"] = lambda: _chain_case(3, 14, 14, 64, 512, 1, 187)                          # four GEMM-2 steps
+CASES["chain_single_image_1x1"] = lambda: _chain_case(3, 1, 1, 64, 256, 1, 188)                # every tap but the centre masked
+
+
 def run_case(name):
     out = CASES[name]()
     err, tol = out

@@ -276,3 +276,15 @@ def eca_gate(sums, inv_count, w, gate_act="sigmoid"):
     ffi.check(lib.tfimm_hip_eca_gate(ptr(sums), float(inv_count), ptr(w), ptr(gate), B, Cc, int(w.shape[0]),
                                      ffi.ACT[gate_act], stream()), "eca_gate")
     return gate
+
+
+def conv_chain(x, wt1, b1, wt2, b2, residual, *, KH, KW, stride, pad, OH, OW, C1, N2, act1="relu", act2="relu"):
+    B, H, W, Cin = x.shape
+    d = ffi.ChainDesc()
+    out = torch.empty(B * OH * OW, N2, dtype=torch.bfloat16, device=DEV)
+    d.x, d.w1, d.b1, d.w2, d.b2, d.residual, d.out = ptr(x), ptr(wt1), ptr(b1), ptr(wt2), ptr(b2), ptr(residual), ptr(out)
+    d.B, d.H, d.W, d.Cin, d.KH, d.KW, d.stride, d.pad_t, d.pad_l, d.OH, d.OW = B, H, W, Cin, KH, KW, stride, pad, pad, OH, OW
+    d.C1, d.N2, d.ldw1, d.ldw2, d.ldr, d.ldc = C1, N2, wt1.shape[1], wt2.shape[1], N2, N2
+    d.act1, d.act2 = ffi.ACT[act1], ffi.ACT[act2]
+    ffi.check(lib.tfimm_hip_conv_chain(C.byref(d), stream()), "conv_chain")
+    return out
