@@ -395,6 +395,16 @@ TFIMM_API int tfimm_hip_avg_pool(const void* x, void* y, int B, int H, int W, in
 TFIMM_API int tfimm_hip_eca_gate(const float* sums, float inv_count, const float* w, float* gate, int B, int C, int k,
                        int gate_act, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * tfimm_hip_grouped_conv3x3: ZeroPadding2D(1) + Conv2D(3x3, stride, groups) (+ folded BatchNorm + activation) for
+ * groups of at most 32 channels with equal input and output width -- ResNeXt's conv2 (resnet.py:229-241).  Runs as
+ * 32-channel super-groups: 32 / (C / groups) times the useful multiply-accumulates instead of `groups` times for the
+ * dense block-diagonal expansion.  x / y: bf16 NHWC, C % 32 == 0; wfrag: the kernel packed per MFMA lane by
+ * tfimm/engine/pack.py pack_grouped3x3 ([C / 32][18][64] 16-byte fragments); bias: fp32 [C].
+ * ------------------------------------------------------------------------------------- */
+TFIMM_API int tfimm_hip_grouped_conv3x3(const void* x, const void* wfrag, const float* bias, void* y, int B, int H, int W,
+                              int C, int stride, int act, void* stream);
+
 /* hipMemsetAsync on the library's own HIP runtime (zeroing accumulation buffers such as the
  * dwconv sum_out) -- avoids a second runtime instance being loaded by the host language. */
 TFIMM_API int tfimm_hip_memset_async(void* dst, int value, size_t bytes, void* stream);

@@ -376,3 +376,102 @@ extern "C" int tfimm_hip_eca_gate(const float* sums, float inv_count, const floa
                C, k, gate_act);
   return 0;
 }
+
+// =====================================================================================================================
+// grouped 3x3 convolution (ResNeXt, resnet.py:229-236: Conv2D(groups = cardinality) between ZeroPadding2D(1) and bn2)
+// =====================================================================================================================
+// Groups of w = C / groups <= 32 channels (input and output width of a group are equal).  A dense kernel over the
+// block-diagonal expansion multiplies C x C per tap -- `groups` times the useful work; here a wave owns ONE super-group
+// of 32 output channels, whose inputs are exactly the same 32 channels, and multiplies 32 x 32 per tap (32 / w times the
+// useful work, 1x at w = 32):
+//   * the super-group's 9 x [32 x 32] weights (block-diagonal inside the 32 x 32) stay in REGISTERS for the whole kernel
+//     as 18 MFMA A fragments (host-packed per lane: pack.pack_grouped3x3);
+//   * a wave walks 32-pixel tiles; the B operand of v_mfma_f32_32x32x16_bf16 (one pixel per lane, 8 consecutive input
+//     channels) is a 16-byte global load per lane and k-step straight from the NHWC tensor -- taps outside the image are
+//     zeroed in the register -- no LDS at all;
+//   * the 4 waves of a workgroup take 4 neighbouring super-groups of the SAME pixels, so together they read whole
+//     256-byte runs of each pixel;
+//   * D[n][m] = W . X^T leaves a lane with 4 consecutive channels of its pixel per accumulator quad: bias (folded BN),
+//     activation, 8-byte stores.
+__global__ __launch_bounds__(256, 2) void grouped_conv3x3_kernel(const bf16_t* __restrict__ x, const uint4* __restrict__ wfrag,
+                                                                 const float* __restrict__ bias, bf16_t* __restrict__ y,
+                                                                 int B, int H, int W, int C, int stride, int OH, int OW,
+                                                                 int act, int n_tiles, int tiles_per_block) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int frow = lane & 31, fhi = lane >> 5;
+  const int sg = blockIdx.y * 4 + wave;                 // super-group: channels [32 sg, 32 sg + 32)
+  if (sg * 32 >= C) return;
+  bf16x8 wf[18];
+#pragma unroll
+  for (int ks = 0; ks < 18; ++ks) wf[ks] = __builtin_bit_cast(bf16x8, wfrag[((size_t)sg * 18 + ks) * 64 + lane]);
+  f32x4 bq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 b4 = *reinterpret_cast<const float4*>(bias + sg * 32 + q * 8 + fhi * 4);
+    bq[q] = f32x4{b4.x, b4.y, b4.z, b4.w};
+  }
+  const ActParams actp = make_act(act);
+  const int64_t M = (int64_t)B * OH * OW;
+  const int t0 = blockIdx.x * tiles_per_block;
+  const int t1 = min(n_tiles, t0 + tiles_per_block);
+  for (int t = t0; t < t1; ++t) {
+    const int64_t m = (int64_t)t * 32 + frow;
+    const bool mok = m < M;
+    const int64_t mm = mok ? m : 0;
+    const int b = (int)(mm / ((int64_t)OH * OW));
+    const int rem = (int)(mm - (int64_t)b * OH * OW);
+    const int oy = rem / OW, ox = rem - oy * OW;
+    const int iy0 = oy * stride - 1, ix0 = ox * stride - 1;
+    const bf16_t* xb = x + (size_t)b * H * W * C + sg * 32 + fhi * 8;
+    uint4 xf[18];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int iy = iy0 + tap / 3, ix = ix0 + tap % 3;
+      const bool ok = mok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const bf16_t* px = xb + ((size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * C;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const uint4 v = *reinterpret_cast<const uint4*>(px + half * 16);
+        xf[tap * 2 + half] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+      }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 18; ++ks)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], __builtin_bit_cast(bf16x8, xf[ks]), acc, 0, 0, 0);
+    if (mok) {
+      bf16_t* py = y + (size_t)m * C + sg * 32 + fhi * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float v0 = act1(acc[q * 4 + 0] + bq[q][0], actp), v1 = act1(acc[q * 4 + 1] + bq[q][1], actp);
+        const float v2 = act1(acc[q * 4 + 2] + bq[q][2], actp), v3 = act1(acc[q * 4 + 3] + bq[q][3], actp);
+        *reinterpret_cast<uint2*>(py + q * 8) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
+      }
+    }
+  }
+}
+
+extern "C" int tfimm_hip_grouped_conv3x3(const void* x, const void* wfrag, const float* bias, void* y, int B, int H, int W,
+                                         int C, int stride, int act, void* stream) {
+  if (!x || !wfrag || !bias || !y) TFIMM_FAIL(TFIMM_EINVAL, "grouped_conv3x3: null pointer");
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 31) || (stride != 1 && stride != 2))
+    TFIMM_FAIL(TFIMM_EINVAL, "grouped_conv3x3: bad shape (C must be a multiple of 32, stride 1 or 2)");
+  if (((uintptr_t)x | (uintptr_t)wfrag | (uintptr_t)bias | (uintptr_t)y) & 15)
+    TFIMM_FAIL(TFIMM_EINVAL, "grouped_conv3x3: pointers must be 16-byte aligned");
+  const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
+  const int64_t M = (int64_t)B * OH * OW;
+  const int64_t n_tiles = cdiv64(M, 32);
+  if (n_tiles > 0x7fffffffLL) TFIMM_FAIL(TFIMM_EINVAL, "grouped_conv3x3: too many pixels");
+  const int gy = (C / 32 + 3) / 4;
+  // enough workgroups to fill the chip a few times over, each keeping its weights for many tiles
+  int64_t gx = cdiv64(2048, gy);
+  if (gx > n_tiles) gx = n_tiles;
+  const int per = (int)cdiv64(n_tiles, gx);
+  gx = cdiv64(n_tiles, per);
+  TFIMM_LAUNCH(grouped_conv3x3_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+               (const uint4*)wfrag, bias, (bf16_t*)y, B, H, W, C, stride, OH, OW, act, (int)n_tiles, per);
+  return 0;
+}

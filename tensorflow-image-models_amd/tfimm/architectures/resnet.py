@@ -80,6 +80,8 @@ class ResNetConfig(ModelConfig):
             self.test_input_size = self.input_size
 
 
+#: largest dense block-diagonal expansion of a grouped 3x3 kernel the fallback path accepts (bytes of bf16 per block)
+_DENSE_GROUPED_LIMIT = 160 * 2**20
 _GN_GROUPS, _GN_EPS = 32, 1e-5      # GroupNormalization defaults (layers/norm.py:128-139, layers/factory.py:55-56)
 
 
@@ -289,11 +291,23 @@ class ResNet(Model):
                 y = conv_norm(x, p + "/conv1/kernel", p + "/bn1", act=act, cite="resnet.py:269-271")
                 k2 = p + "/conv2/kernel"
                 kw2 = {}
-                if c.cardinality > 1:
-                    # ResNeXt (resnet.py:229-236, Conv2D(groups=cardinality)): the grouped 3x3 runs as a dense
-                    # convolution over the block-diagonal expansion of its kernel -- exact (the extra products are
-                    # x * 0), at cardinality x the multiply-accumulates
-                    k2 = b.define(k2 + ":dense", _expand_grouped_kernel(b.wget(k2), c.cardinality))
+                grouped = None
+                if c.cardinality > 1 and not gn:
+                    # ResNeXt (resnet.py:229-236, Conv2D(groups=cardinality)): 32-channel super-groups on the MFMA
+                    # (tfimm_hip_grouped_conv3x3) when a group has at most 32 channels
+                    grouped = b.grouped_conv3x3(y, k2, c.cardinality, stride=cstride, bn=p + "/bn2", bn_eps=eps, act=act,
+                                                cite="resnet.py:229-241,273-276")
+                if c.cardinality > 1 and grouped is None:
+                    # wider groups: a dense convolution over the block-diagonal expansion of the kernel -- exact (the
+                    # extra products are x * 0), at cardinality x the multiply-accumulates and weight bytes
+                    kg = b.wget(k2)
+                    dense_bytes = 9 * kg.shape[3] * kg.shape[3] * 2
+                    if dense_bytes > _DENSE_GROUPED_LIMIT:
+                        raise NotImplementedError(
+                            f"{c.name}: grouped 3x3 with {kg.shape[2]} channels per group would expand to a "
+                            f"{dense_bytes / 2**20:.0f} MiB dense kernel per block (limit {_DENSE_GROUPED_LIMIT / 2**20:.0f} MiB); "
+                            "tfimm_hip_grouped_conv3x3 covers groups of at most 32 channels")
+                    k2 = b.define(k2 + ":dense", _expand_grouped_kernel(kg, c.cardinality))
                     kw2["flops_k"] = 9 * y.C // c.cardinality
                 fused = None
                 if not gn and not gated and not use_aa and c.cardinality == 1 and act == "relu":
@@ -304,7 +318,8 @@ class ResNet(Model):
                 if fused is not None:
                     y = fused
                 else:
-                    y = conv_norm(y, k2, p + "/bn2", stride=cstride, padding=1, act=act, cite="resnet.py:273-276", **kw2)
+                    y = grouped if grouped is not None else conv_norm(y, k2, p + "/bn2", stride=cstride, padding=1, act=act,
+                                                                      cite="resnet.py:273-276", **kw2)
                     if use_aa:
                         y = b.blur_pool(y, stride, cite="resnet.py:277-278")
                     y = conv_norm(y, p + "/conv3/kernel", p + "/bn3", cite="resnet.py:280-290", **last)

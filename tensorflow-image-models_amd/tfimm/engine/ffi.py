@@ -110,6 +110,7 @@ SYMBOLS = {
     "tfimm_hip_blur_pool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tfimm_hip_avg_pool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "tfimm_hip_eca_gate": (_i, [_vp, _f, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tfimm_hip_grouped_conv3x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "tfimm_hip_bias_act": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "tfimm_hip_memset_async": (_i, [_vp, _i, C.c_size_t, _vp]),
 }

@@ -108,6 +108,8 @@ class Program:
                 total += a["flops"]
             elif op.kind == "dwconv":
                 total += 2 * a["OH"] * a["OW"] * a["C"] * a["k"] * a["k"]
+            elif op.kind == "grouped_conv":
+                total += a["flops"]
         return total
 
     def weight_bytes(self) -> int:
@@ -354,6 +356,29 @@ class Builder:
         p.add("conv_chain", ins, out, consts, cite=cite, H=x.H, W=x.W, Cin=cin, KH=kh, KW=kw, stride=stride, pad=pad,
               OH=OH, OW=OW, C1=c1, N2=n2, ldw1=wt1.shape[1], ldw2=wt2.shape[1], act1=act1, act2=act2,
               has_residual=residual is not None, flops=2 * OH * OW * (c1 * kh * kw * cin + n2 * c1))
+        return out
+
+    def grouped_conv3x3(self, x: TRef, kernel: str, groups: int, *, stride=1, bn: Optional[str] = None, bn_eps=1e-5,
+                        act="", cite="") -> Optional[TRef]:
+        """ZeroPadding2D(1) + Conv2D(3x3, stride, groups) + folded BN + activation on 32-channel super-groups
+        (tfimm_hip_grouped_conv3x3).  None when the group width does not fit that kernel (> 32 channels per group, or
+        32 not a multiple of it): the caller then falls back to the dense block-diagonal expansion."""
+        p = self.p
+        k = self.wget(kernel)
+        kh, kw, w, c = k.shape
+        if ((kh, kw) != (3, 3) or c != w * groups or x.C != c or w > 32 or 32 % w or c % 32 or stride not in (1, 2)
+                or os.environ.get("TFIMM_NO_GROUPED", "0") == "1"):
+            return None
+        scale = shift = None
+        if bn is not None:
+            scale, shift = self.bn(bn, bn_eps)
+        wfrag = pack.pack_grouped3x3(k, groups, scale)
+        bvec = np.zeros(c, np.float32) if shift is None else np.ascontiguousarray(shift, dtype=np.float32)
+        OH, OW = (x.H + 2 - 3) // stride + 1, (x.W + 2 - 3) // stride + 1
+        out = p.new_tensor(OH * OW, c, OH, OW, name=kernel)
+        consts = {"w": p.new_const(wfrag, kernel), "bias": p.new_const(bvec, kernel + ":bias")}
+        p.add("grouped_conv", [x], out, consts, cite=cite, H=x.H, W=x.W, C=c, stride=stride, act=act,
+              flops=2 * OH * OW * c * 9 * w)
         return out
 
     def dense(self, x: TRef, kernel: str, bias: Optional[str] = None, *, act="",
@@ -778,6 +803,10 @@ class Plan:
                 d.act1, d.act2 = ffi.ACT[a["act1"]], ffi.ACT[a["act2"]]
                 self._keepalive.append(d)
                 self.calls.append((lib.tfimm_hip_conv_chain, (C.byref(d),)))
+            elif k == "grouped_conv":
+                self.calls.append((lib.tfimm_hip_grouped_conv3x3,
+                                   (self.tptr(op.inputs[0]), self.cptr(op.consts["w"]), self.cptr(op.consts["bias"]),
+                                    self.tptr(op.output), B, a["H"], a["W"], a["C"], a["stride"], ffi.ACT[a["act"]])))
             elif k == "layernorm":
                 xp = self.tptr(op.inputs[0]) + a["x_byte_offset"]
                 self.calls.append((lib.tfimm_hip_layernorm,

@@ -129,3 +129,30 @@ def chain_k_order(c1: int) -> np.ndarray:
     assert c1 % 16 == 0
     inner = np.array([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
     return (np.arange(0, c1, 16)[:, None] + inner[None, :]).reshape(-1)
+
+
+def pack_grouped3x3(kernel: np.ndarray, groups: int, scale: Optional[np.ndarray]) -> np.ndarray:
+    """Grouped 3x3 kernel (3, 3, C / groups, C), input and output width of a group equal and <= 32 -> the per-lane MFMA A
+    fragments tfimm_hip_grouped_conv3x3 keeps in registers: uint16 [C / 32][18][64][8].  Super-group sg = output channels
+    [32 sg, 32 sg + 32); its inputs are the same 32 channels.  Fragment ks = 2 tap + half, lane l: output channel
+    32 sg + (l & 31), input channels 32 sg + 16 half + 8 (l >> 5) + 0..7 (zero where the two are in different groups)."""
+    kh, kw, w, c = kernel.shape
+    assert (kh, kw) == (3, 3) and c == w * groups and w <= 32 and 32 % w == 0 and c % 32 == 0, kernel.shape
+    k = kernel.astype(np.float32)
+    if scale is not None:
+        k = k * scale.reshape(1, 1, 1, c)
+    nsg = c // 32
+    dense = np.zeros((nsg, 9, 32, 32), dtype=np.float32)          # [sg][tap][out i][in cl]
+    for sg in range(nsg):
+        for i in range(32):
+            n = sg * 32 + i
+            g = n // w
+            lo = g * w - sg * 32                                      # first local input channel of that group
+            dense[sg, :, i, lo:lo + w] = k[:, :, :, n].reshape(9, w)
+    lane = np.arange(64)
+    out = np.zeros((nsg, 18, 64, 8), dtype=np.float32)
+    for tap in range(9):
+        for half in range(2):
+            cl = half * 16 + (lane >> 5)[:, None] * 8 + np.arange(8)[None, :]      # (64, 8)
+            out[:, tap * 2 + half] = dense[:, tap][:, (lane & 31)[:, None], cl]
+    return to_bf16_bits(out).reshape(nsg, 18, 64, 8)

@@ -889,6 +889,30 @@ CASES["chain_n512"] = lambda: _chain_case(3, 14, 14, 64, 512, 1, 187)           
 CASES["chain_single_image_1x1"] = lambda: _chain_case(3, 1, 1, 64, 256, 1, 188)                # every tap but the centre masked
 
 
+def _grouped_case(B, Hh, Ww, Cc, groups, stride, seed, act="relu"):
+    import hip_ops as H
+    r = _rng(seed)
+    w = Cc // groups
+    x = _bf(r.standard_normal((B, Hh, Ww, Cc)))
+    k = (r.standard_normal((3, 3, w, Cc)) / math.sqrt(9 * w)).astype(np.float32)
+    scale = r.uniform(0.5, 1.5, Cc).astype(np.float32)
+    shift = r.standard_normal(Cc).astype(np.float32)
+    wfrag = pack.pack_grouped3x3(k, groups, scale)
+    kf = _bf(k * scale.reshape(1, 1, 1, -1))
+    y = O.conv2d(O.zero_pad2d(torch.from_numpy(x), 1), torch.from_numpy(kf), None, stride=stride, groups=groups)
+    y = O.activation(y + torch.from_numpy(shift), act).numpy()
+    got = H.grouped_conv3x3(H.dev_bf16(x), H.dev_bits(wfrag.reshape(-1, 8)), H.dev_f32(shift), stride, act)
+    H.sync()
+    return _err(_cpu(got), y), TOL_BF16
+
+
+CASES["grouped3x3_c128_g32_56x56"] = lambda: _grouped_case(2, 56, 56, 128, 32, 1, 190)            # resnext50_32x4d layer 1: 4 channels per group
+CASES["grouped3x3_c256_g32_s2_odd"] = lambda: _grouped_case(2, 29, 23, 256, 32, 2, 191)           # 8 per group, stride 2, odd sizes
+CASES["grouped3x3_c1024_g32_7x7"] = lambda: _grouped_case(3, 7, 7, 1024, 32, 1, 192)              # 32 per group: dense 32 x 32 blocks
+CASES["grouped3x3_c64_g4_tiny"] = lambda: _grouped_case(1, 3, 5, 64, 4, 1, 193, act="")           # 16 per group, partial pixel tile
+CASES["grouped3x3_c96_g6_many_tiles"] = lambda: _grouped_case(9, 40, 40, 96, 6, 1, 194)           # 3 super-groups: last workgroup half empty
+
+
 def run_case(name):
     out = CASES[name]()
     err, tol = out

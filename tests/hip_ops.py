@@ -288,3 +288,12 @@ def conv_chain(x, wt1, b1, wt2, b2, residual, *, KH, KW, stride, pad, OH, OW, C1
     d.act1, d.act2 = ffi.ACT[act1], ffi.ACT[act2]
     ffi.check(lib.tfimm_hip_conv_chain(C.byref(d), stream()), "conv_chain")
     return out
+
+
+def grouped_conv3x3(x, wfrag, bias, stride, act=""):
+    B, H, W, Cc = x.shape
+    OH, OW = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    out = torch.empty(B, OH, OW, Cc, dtype=torch.bfloat16, device=DEV)
+    ffi.check(lib.tfimm_hip_grouped_conv3x3(ptr(x), ptr(wfrag), ptr(bias), ptr(out), B, H, W, Cc, stride, ffi.ACT[act],
+                                            stream()), "grouped_conv3x3")
+    return out

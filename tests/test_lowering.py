@@ -98,15 +98,45 @@ def test_resnext_and_eca_lower_to_existing_ops_and_the_oracle_runs_them():
     import oracle
     kinds, prog = _kinds("resnext_test_model")
     assert kinds[1] == "stem_pool"
-    grouped = [op for op in prog.ops if op.kind == "gemm" and op.attrs.get("KH") == 3]
-    # algorithmic K of a grouped 3x3 = 9 * Cin / groups although the dense expansion multiplies 9 * Cin
-    assert all(op.attrs["K_true"] * 4 == 9 * op.attrs["Cin"] for op in grouped)
+    # widths 16 / 32 / 48 / 64 in 4 groups: 32 and 64 run on 32-channel super-groups (tfimm_hip_grouped_conv3x3); 16 is
+    # not a whole super-group and 48 has 12-channel groups (32 % 12 != 0): those take the dense block-diagonal expansion,
+    # whose algorithmic K stays 9 * Cin / groups
+    grouped = [op for op in prog.ops if op.kind == "grouped_conv"]
+    dense = [op for op in prog.ops if op.kind == "gemm" and op.attrs.get("KH") == 3]
+    assert [op.attrs["C"] for op in grouped] == [32, 64] and [op.attrs["Cin"] for op in dense] == [16, 48]
+    assert all(op.attrs["K_true"] * 4 == 9 * op.attrs["Cin"] for op in dense)
+    assert all(op.attrs["flops"] == 2 * prog.tensors[op.output].rows * op.attrs["C"] * 9 * (op.attrs["C"] // 4) for op in grouped)
     kinds, _ = _kinds("ecaresnet_test_model")
     assert kinds.count("scale_channels") == 4 and kinds.count("mean_rows") == 5     # 4 gates + the head pooling
     for name in ("resnext_test_model", "ecaresnet_test_model"):
         m = tfimm.create_model(name)
         y = oracle.forward(m.cfg, synthetic_weights(m), mc.make_input(m.cfg, 2))
         assert y.shape == (2, 10) and np.isfinite(y).all()
+
+
+def test_resnet50_stage1_tails_are_one_launch_each():
+    """conv2 + bn2 + relu + conv3 + bn3 + shortcut + relu of the three stage-1 blocks lower to tfimm_hip_conv_chain (the
+    64-channel intermediate never reaches HBM); the algorithmic FLOP count is unchanged; TFIMM_NO_CHAIN=1 keeps two GEMMs"""
+    kinds, prog = _kinds("resnet50")
+    chains = [op for op in prog.ops if op.kind == "conv_chain"]
+    assert len(chains) == 3 and all((op.attrs["H"], op.attrs["C1"], op.attrs["N2"], op.attrs["has_residual"]) == (56, 64, 256, True)
+                                    for op in chains)
+    assert abs(prog.flops_per_image() / 1e9 - 8.178) < 0.01
+    kinds, _ = _kinds("resnet50", size=(256, 256))          # rows of 64 pixels: wider than the kernel's input strip
+    assert "conv_chain" not in kinds
+
+
+def test_chain_switch(monkeypatch):
+    monkeypatch.setenv("TFIMM_NO_CHAIN", "1")
+    kinds, prog = _kinds("resnet50")
+    assert "conv_chain" not in kinds and abs(prog.flops_per_image() / 1e9 - 8.178) < 0.01
+
+
+def test_wide_grouped_convolutions_are_refused_with_a_reason():
+    """ig_resnext101_32x48d: 48..384 channels per group -- neither the super-group kernel nor a sane dense expansion"""
+    m = tfimm.create_model("ig_resnext101_32x32d")
+    with pytest.raises(NotImplementedError, match="MiB dense kernel"):
+        m.program(64, 64)
 
 
 def test_every_registered_resnet_is_supported():
