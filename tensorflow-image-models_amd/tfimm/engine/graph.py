@@ -12,6 +12,7 @@ carry its spatial extent ``(H, W)``.
 """
 import ctypes as C
 import os
+import zlib
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -48,10 +49,14 @@ class TRef:
 
 @dataclass
 class Const:
-    """Device constant (packed weight).  ``host`` is a numpy array: uint16 = bf16 bits."""
+    """Device constant (packed weight).  ``host`` is a numpy array (uint16 = bf16 bits); it is released once the constant
+    is on the device unless ``keep_host`` (constants a kernel takes by HOST pointer)."""
     id: int
-    host: np.ndarray
+    host: Optional[np.ndarray]
     name: str = ""
+    nbytes: int = 0
+    keep_host: bool = False
+    key: Optional[tuple] = None      # (name, shape, dtype, checksum): identical constants of other programs share one upload
 
 
 @dataclass
@@ -75,6 +80,7 @@ class Program:
         self.outputs: Dict[str, TRef] = {}
         self._dev_consts = None
         self._dev_consts_device = None
+        self.const_cache: Optional[dict] = None     # set by the owning Model
 
     # -- construction helpers -------------------------------------------------------------
     def new_tensor(self, rows, C, H=0, W=0, dtype="bf16", name="") -> TRef:
@@ -82,8 +88,10 @@ class Program:
         self.tensors.append(t)
         return t
 
-    def new_const(self, host: np.ndarray, name="") -> int:
-        c = Const(len(self.consts), np.ascontiguousarray(host), name)
+    def new_const(self, host: np.ndarray, name="", keep_host=False) -> int:
+        h = np.ascontiguousarray(host)
+        key = (name, h.shape, h.dtype.str, zlib.crc32(h.view(np.uint8).reshape(-1)))
+        c = Const(len(self.consts), h, name, h.nbytes, keep_host, key)
         self.consts.append(c)
         return c.id
 
@@ -113,7 +121,7 @@ class Program:
         return total
 
     def weight_bytes(self) -> int:
-        return sum(c.host.nbytes for c in self.consts)
+        return sum(c.nbytes for c in self.consts)
 
     # -- buffer planning ---------------------------------------------------------------------
     def plan_buffers(self) -> Tuple[Dict[int, int], List[int]]:
@@ -156,18 +164,28 @@ class Program:
 
     # -- device side ------------------------------------------------------------------------
     def upload(self, device="cuda"):
+        """Packed constants -> device.  ``self.const_cache`` (the owning model's, shared by all its programs: another
+        input size, the feature-returning variant) maps a constant's key to its device tensor, so identical constants are
+        uploaded once; host copies are dropped afterwards."""
         import torch
         if self._dev_consts is not None and self._dev_consts_device == device:
             return
         self._dev_consts_device = device
+        cache = self.const_cache if self.const_cache is not None else {}
         dev = []
         for c in self.consts:
-            h = c.host
-            if h.dtype == np.uint16:
-                t = torch.from_numpy(h.view(np.int16).copy()).to(device)
-            else:
-                t = torch.from_numpy(h.copy()).to(device)
+            ck = (device,) + c.key
+            t = cache.get(ck)
+            if t is None:
+                h = c.host
+                if h.dtype == np.uint16:
+                    t = torch.from_numpy(h.view(np.int16).copy()).to(device)
+                else:
+                    t = torch.from_numpy(h.copy()).to(device)
+                cache[ck] = t
             dev.append(t)
+            if not c.keep_host and device != "cpu":
+                c.host = None
         self._dev_consts = dev
 
     def make_plan(self, batch: int, device: str = "cuda") -> "Plan":
@@ -522,7 +540,8 @@ class Builder:
         out = p.new_tensor(qkv.rows, d, qkv.H, qkv.W, name=name or prefix)
         consts = {}
         for role, nm in (("wl", "proj_l/kernel"), ("bl", "proj_l/bias"), ("ww", "proj_w/kernel"), ("bw", "proj_w/bias")):
-            consts[role] = p.new_const(np.ascontiguousarray(self.wget(f"{prefix}/{nm}"), dtype=np.float32), f"{prefix}/{nm}")
+            consts[role] = p.new_const(np.ascontiguousarray(self.wget(f"{prefix}/{nm}"), dtype=np.float32), f"{prefix}/{nm}",
+                                       keep_host=True)
         n = qkv.rows
         p.add("talking_heads_attention", [qkv], out, consts, cite=cite, heads=heads, hd=hd, scale=float(scale),
               n_tokens=n, flops=4 * heads * n * n * hd + 4 * heads * heads * n * n)

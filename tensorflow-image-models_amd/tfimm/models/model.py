@@ -96,6 +96,8 @@ class Model:
         self._specs = self.weight_specs()
         self._weights: Dict[str, np.ndarray] = winit.initialize(self._specs, mode=init, seed=seed)
         self._programs: Dict[tuple, Program] = {}
+        #: device copies of packed constants, shared by every program of this model (engine/graph.py Program.upload)
+        self._const_cache: Dict[tuple, object] = {}
         self._plans: Dict[tuple, object] = {}
         #: hipGraph recordings of plans that have been used more than once: (plan key, input dtype) -> CapturedPlan
         self._captured: Dict[tuple, object] = {}
@@ -153,6 +155,7 @@ class Model:
                 raise KeyError(f"{self.name}: {len(missing)} weights missing from the provided set, e.g. {missing[:5]}")
         self._weights.update(staged)
         self._programs.clear()
+        self._const_cache.clear()
         self._plans.clear()
         self._captured.clear()
         self._plan_uses.clear()
@@ -174,6 +177,7 @@ class Model:
         key = (H, W, bool(want_features))
         if key not in self._programs:
             b = Builder(self._weights)
+            b.p.const_cache = self._const_cache
             self.lower(b, H, W, want_features)
             self._programs[key] = b.p
         return self._programs[key]

@@ -158,3 +158,19 @@ def test_group_norm_and_blur_pool_lowering():
     assert [op.attrs["stride"] for op in prog.ops if op.kind == "maxpool"] == [1]         # resnet.py:534
     strided = [op for op in prog.ops if op.kind == "gemm" and op.attrs.get("KH") == 3 and op.attrs.get("stride") == 2]
     assert not strided                     # the blur layer takes care of the stride (resnet.py:132, 233)
+
+
+def test_programs_of_one_model_share_their_packed_constants():
+    """a second program of the same model (other input size, feature variant) re-uses the uploaded constants: the cache is
+    keyed by (name, shape, dtype, checksum), so only size-dependent constants are new (device = "cpu": no GPU needed)"""
+    m = tfimm.create_model("resnet50_mini_test_model")
+    m.set_weights(synthetic_weights(m))
+    p1, p2, p3 = m.program(64, 64), m.program(96, 64), m.program(64, 64, want_features=True)
+    p1.upload("cpu")
+    n1 = len(m._const_cache)
+    p2.upload("cpu")
+    p3.upload("cpu")
+    assert n1 > 10 and len(m._const_cache) == n1          # nothing size- or feature-dependent in a ResNet's constants
+    assert all(a is b for a, b in zip(p1._dev_consts, p3._dev_consts))
+    m.set_weights(synthetic_weights(m, 5))
+    assert not m._const_cache
