@@ -354,6 +354,34 @@ typedef struct tfimm_chain_desc {
 TFIMM_API int tfimm_hip_conv_chain(const tfimm_chain_desc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * tfimm_hip_expand_dwconv: the front half of an inverted-residual block in one launch --
+ *   conv_pw (1x1, Cin -> C) + bn1 + act1, then conv_dw (k x k depthwise, stride) + bn2 + act2, optionally the
+ *   squeeze sums of the result (efficientnet_blocks.py:438-445, InvertedResidual.call up to `se`).
+ * The expanded tensor exists only in LDS, rounded to bf16 exactly where the two-launch path (tfimm_hip_gemm +
+ * tfimm_hip_dwconv) rounds the tensor it stores; depthwise accumulation is fp32.
+ *   x    bf16 [B][H][W][Cin], Cin % 8 == 0, Cin <= 32
+ *   w1   expand weights (BN scale folded) as MFMA fragments: bf16 [Cpad/32][2][64][8], element
+ *        [cc][ks][lane][j] = W1[k = 16 ks + 8 (lane >> 5) + j][c = 32 cc + (lane & 31)], zero for k >= Cin, c >= C
+ *   b1, b2  fp32 [Cpad] folded BN shifts;  wdw  fp32 [k*k][Cpad] depthwise taps (BN scale folded), zero padded
+ *   y    bf16 [B][OH][OW][C];  sum_out  fp32 [B][C] (zeroed by the caller) or NULL
+ * k in {3, 5}, stride in {1, 2}, explicit top / left zero padding of the EXPANDED tensor (bottom / right follow from
+ * OH, OW).  Anything else returns TFIMM_EUNSUP and the caller runs the two launches.
+ * ------------------------------------------------------------------------------------- */
+typedef struct tfimm_expand_dw_desc {
+  const void* x;
+  const void* w1;
+  const float* b1;
+  const float* wdw;
+  const float* b2;
+  void* y;
+  float* sum_out;
+  int32_t B, H, W, Cin, C, Cpad, k, stride, pad_t, pad_l, OH, OW;
+  int32_t act1, act2;
+} tfimm_expand_dw_desc;
+
+TFIMM_API int tfimm_hip_expand_dwconv(const tfimm_expand_dw_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * tfimm_hip_attention_probs: probs[b][h][i][j] = softmax_j(scale * q[b,i,h,:] . k[b,j,h,:]) in fp32 --
  * the attention map ViTMultiHeadAttention.call returns as features["attn"] when return_features=True
  * (vit.py:160-163; ViT.forward_features stores it as "block_<j>/attn", vit.py:447-450).  qkv: bf16

@@ -1,0 +1,277 @@
+// tfimm_hip_expand_dwconv: the front half of an inverted-residual (MBConv) block as ONE kernel (gfx950)
+//     conv_pw (1x1, Cin -> C) + bn1 + act  ->  conv_dw (k x k depthwise, stride s) + bn2 + act  [-> SE squeeze sums]
+// (efficientnet_blocks.py:438-445; InvertedResidual.call up to the squeeze-excite).  As two launches the expanded tensor --
+// 6x the block's input, the largest tensor of the network -- is written by the GEMM and read back by the depthwise kernel, and
+// the GEMM with K = 24 / 32 is one k-step followed by an activation over C outputs per pixel that its epilogue pays for with the
+// MFMA pipe idle.  Here the expanded activations exist only in LDS:
+//
+//   * a workgroup (8 waves) owns an OTH x OTW tile of OUTPUT pixels of one image and walks the expanded channels in chunks of
+//     32.  The input pixels the tile needs (its halo, IH x IW) are fetched once into LDS (64 bytes per pixel, K padded to 32,
+//     16-byte chunks XOR-swizzled for the fragment reads) and serve every chunk;
+//   * phase 1 (per chunk): E[pixel][32 channels] = act(W1^T . x + b1) for every halo pixel by v_mfma_f32_32x32x16_bf16 with
+//     the weights as the A operand (host-packed fragments, 2 k-steps), so a lane ends up with 16 channels of ONE pixel; pixels
+//     outside the image are zeroed (TF pads the EXPANDED tensor with zeros, not the expansion of zero pixels), rounded to bf16
+//     exactly as the two-launch path rounds the tensor it stores, and written to LDS at a pitch of 72 bytes per pixel
+//     (conflict-free 8-byte writes, no address arithmetic on the read side);
+//   * phase 2 (per chunk): a thread owns a channel PAIR and one output column and marches down its rows; every halo row costs K
+//     4-byte LDS reads at immediate offsets and feeds the K output rows it contributes to with packed FMAs (taps as float2 in
+//     registers, read per chunk from an LDS copy).  bias + activation, 4-byte stores (a wave writes 64-byte runs of 4 pixels),
+//     squeeze sums of the stored values through LDS atomics and one global atomic per (workgroup, channel).
+//   Both phases are VALU-bound (the activation: two quarter-rate transcendentals per value for swish); two workgroups share a
+//   CU so one's global loads / stores sit under the other's arithmetic.  HBM traffic: input halo once + output once.
+#include "common.h"
+
+namespace {
+
+struct MbArgs {
+  const bf16_t* x;
+  const uint4* w1;
+  const float* b1;
+  const float* wdw;
+  const float* b2;
+  bf16_t* y;
+  float* sums;
+  int H, W, Cin, C, Cpad, pad_t, pad_l, OH, OW, tiles_x, act1, act2;
+};
+
+template <int K, int S, int OTH, int OTW>
+struct MbGeom {
+  static constexpr int NT = 512, NSLOT = 32;
+  static constexpr int RG = NSLOT / OTW, RPT = OTH / RG;
+  static_assert(NSLOT % OTW == 0 && OTH % RG == 0, "tile does not map onto 32 column slots");
+  static constexpr int IH = (OTH - 1) * S + K, IW = (OTW - 1) * S + K, NPX = IH * IW, NBLK = (NPX + 31) / 32;
+  static constexpr int JB = (NBLK + 7) / 8;
+  static constexpr int NR = (RPT - 1) * S + K;
+  static constexpr int XP = 64, EP = 72;
+  static constexpr int X_BYTES = NPX * XP, E_BYTES = NPX * EP;
+  static constexpr int WD_FLOATS = (K * K + 1) * 32;
+  static constexpr int LDS = X_BYTES + E_BYTES + WD_FLOATS * 4 + 64 * 4;
+  static_assert(LDS <= 80 * 1024, "two workgroups per CU");
+};
+
+template <int K, int S, int OTH, int OTW>
+__global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
+  using G = MbGeom<K, S, OTH, OTW>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char mb_smem[];
+  unsigned char* Xs = mb_smem;
+  unsigned char* Es = mb_smem + G::X_BYTES;
+  float* Wd = reinterpret_cast<float*>(Es + G::E_BYTES);
+  float* lsum = Wd + G::WD_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.y;
+  const int ty = blockIdx.x / p.tiles_x, tx = blockIdx.x - ty * p.tiles_x;
+  const int oy0 = ty * OTH, ox0 = tx * OTW;
+  const int gy0 = oy0 * S - p.pad_t, gx0 = ox0 * S - p.pad_l;
+
+  // ---- phase 0: the input halo, once per tile ------------------------------------------------------------------------
+  {
+    const int nch = p.Cin >> 3;
+    const bf16_t* xb = p.x + (size_t)b * p.H * p.W * p.Cin;
+#pragma unroll
+    for (int i0 = 0; i0 < G::NPX * 4; i0 += G::NT) {
+      const int i = i0 + tid;
+      if (i < G::NPX * 4) {
+        const int px = i >> 2, c = i & 3;
+        const int iy = px / G::IW, ix = px - iy * G::IW;
+        const int gy = gy0 + iy, gx = gx0 + ix;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (c < nch && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+          v = *reinterpret_cast<const uint4*>(xb + ((size_t)gy * p.W + gx) * p.Cin + c * 8);
+        *reinterpret_cast<uint4*>(Xs + px * G::XP + ((c ^ ((px >> 2) & 3)) << 4)) = v;
+      }
+    }
+    if (tid < 64) lsum[tid] = 0.f;
+  }
+  // which of this lane's halo pixels (one per block it expands) lie inside the image
+  uint32_t vbits = 0;
+#pragma unroll
+  for (int j = 0; j < G::JB; ++j) {
+    const int px = (wave + 8 * j) * 32 + l31;
+    const int iy = px / G::IW, ix = px - iy * G::IW;
+    const bool ok = px < G::NPX && (unsigned)(gy0 + iy) < (unsigned)p.H && (unsigned)(gx0 + ix) < (unsigned)p.W;
+    vbits |= (ok ? 1u : 0u) << j;
+  }
+  const ActParams a1 = make_act(p.act1), a2 = make_act(p.act2);
+  const int nchunks = p.Cpad >> 5;
+  // phase-2 role of this thread
+  const int cp = tid & 15, slot = tid >> 4, col = slot % OTW, rg = slot / OTW;
+  const uint32_t* ep = reinterpret_cast<const uint32_t*>(Es + ((rg * G::RPT * S) * G::IW + col * S) * G::EP + cp * 4);
+  const tfimm_f32x2* wl = reinterpret_cast<const tfimm_f32x2*>(Wd) + cp;
+  const int ox = ox0 + col;
+  const int oyb = oy0 + rg * G::RPT;
+
+  for (int cc = 0; cc < nchunks; ++cc) {
+    // squeeze sums of the previous chunk: one global atomic per channel, then re-arm that half of the buffer
+    if (p.sums && cc > 0 && tid < 32) {
+      const int h = ((cc - 1) & 1) * 32 + tid, ch = (cc - 1) * 32 + tid;
+      if (ch < p.C) atomicAdd(p.sums + (size_t)b * p.C + ch, lsum[h]);
+      lsum[h] = 0.f;
+    }
+    // ---- phase 1: expand + activation into LDS ------------------------------------------------------------------------
+    bf16x8 af[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) af[ks] = __builtin_bit_cast(bf16x8, p.w1[(size_t)(cc * 2 + ks) * 64 + lane]);
+    f32x4 bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 b4 = *reinterpret_cast<const float4*>(p.b1 + cc * 32 + q * 8 + hi * 4);
+      bq[q] = f32x4{b4.x, b4.y, b4.z, b4.w};
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < G::WD_FLOATS; i0 += G::NT) {
+      const int i = i0 + tid;
+      if (i < G::WD_FLOATS) {
+        const int t = i >> 5, ch = cc * 32 + (i & 31);
+        Wd[i] = t < K * K ? p.wdw[(size_t)t * p.Cpad + ch] : p.b2[ch];
+      }
+    }
+    const int nq = min(4, (p.C - cc * 32 + 7) >> 3);
+#pragma unroll
+    for (int j = 0; j < G::JB; ++j) {
+      const int blk = wave + 8 * j;
+      if (blk < G::NBLK) {
+        const int px = blk * 32 + l31;
+        const int pxr = min(px, G::NPX - 1);
+        const int sw = (pxr >> 2) & 3;
+        const unsigned char* xa = Xs + pxr * G::XP;
+        const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(xa + ((hi ^ sw) << 4));
+        const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(xa + (((2 + hi) ^ sw) << 4));
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], x0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], x1, acc, 0, 0, 0);
+        const uint32_t keep = ((vbits >> j) & 1u) ? 0xffffffffu : 0u;
+        unsigned char* ea = Es + px * G::EP + hi * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (2 * h < nq) {            // wave-uniform: a last chunk of 8 / 16 / 24 channels skips the activation of its padding
+            tfimm_f32x2 v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int q = 2 * h + (e >> 1), r = (e & 1) * 2;
+              v[e] = tfimm_f32x2{acc[q * 4 + r] + bq[q][r], acc[q * 4 + r + 1] + bq[q][r + 1]};
+            }
+            act8p(v, a1);
+            if (px < G::NPX) {
+#pragma unroll
+              for (int qq = 0; qq < 2; ++qq) {
+                const uint32_t u0 = pack_bf2(v[qq * 2][0], v[qq * 2][1]) & keep;
+                const uint32_t u1 = pack_bf2(v[qq * 2 + 1][0], v[qq * 2 + 1][1]) & keep;
+                *reinterpret_cast<uint2*>(ea + (2 * h + qq) * 16) = make_uint2(u0, u1);
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: depthwise taps out of LDS ------------------------------------------------------------------------------
+    {
+      tfimm_f32x2 w[K * K];
+#pragma unroll
+      for (int t = 0; t < K * K; ++t) w[t] = wl[t * 16];
+      const tfimm_f32x2 bias2 = wl[K * K * 16];
+      tfimm_f32x2 acc[G::RPT];
+#pragma unroll
+      for (int r = 0; r < G::RPT; ++r) acc[r] = bias2;
+#pragma unroll
+      for (int j = 0; j < G::NR; ++j) {
+        tfimm_f32x2 v[K];
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          const uint32_t raw = ep[(j * G::IW + kx) * (G::EP / 4)];
+          v[kx] = tfimm_f32x2{__uint_as_float(raw << 16), __uint_as_float(raw & 0xffff0000u)};
+        }
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+          if (j - ky >= 0 && (j - ky) % S == 0 && (j - ky) / S < G::RPT) {
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+              acc[(j - ky) / S] = __builtin_elementwise_fma(v[kx], w[ky * K + kx], acc[(j - ky) / S]);
+          }
+        }
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keeps hipcc from hoisting every row's LDS reads to the top
+      }
+      const int c0 = cc * 32 + cp * 2;
+      const bool cok = c0 < p.C && ox < p.OW;
+      tfimm_f32x2 tot = {0.f, 0.f};
+      bf16_t* yb = p.y + (((size_t)b * p.OH + oyb) * p.OW + ox) * p.C + c0;
+#pragma unroll
+      for (int r0 = 0; r0 < G::RPT; r0 += 4) {
+        tfimm_f32x2 v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (r0 + e < G::RPT) ? acc[(r0 + e < G::RPT) ? r0 + e : 0] : tfimm_f32x2{0.f, 0.f};
+        act8p(v, a2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (r0 + e < G::RPT) {
+            const uint32_t pk = pack_bf2(v[e][0], v[e][1]);
+            if (cok && oyb + r0 + e < p.OH) {
+              *reinterpret_cast<uint32_t*>(yb + (size_t)(r0 + e) * p.OW * p.C) = pk;
+              // the squeeze sees the stored (bf16-rounded) activations, as in tfimm_hip_dwconv
+              tot += tfimm_f32x2{__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)};
+            }
+          }
+        }
+      }
+      if (p.sums) {
+        atomicAdd(&lsum[(cc & 1) * 32 + cp * 2], tot[0]);
+        atomicAdd(&lsum[(cc & 1) * 32 + cp * 2 + 1], tot[1]);
+      }
+    }
+    __syncthreads();
+  }
+  if (p.sums && tid < 32) {
+    const int cl = nchunks - 1;
+    const int ch = cl * 32 + tid;
+    if (ch < p.C) atomicAdd(p.sums + (size_t)b * p.C + ch, lsum[(cl & 1) * 32 + tid]);
+  }
+}
+
+template <int K, int S, int OTH, int OTW>
+int launch_expand_dw(const MbArgs& a0, int B, hipStream_t st) {
+  using G = MbGeom<K, S, OTH, OTW>;
+  MbArgs a = a0;
+  a.tiles_x = (a.OW + OTW - 1) / OTW;
+  const int tiles_y = (a.OH + OTH - 1) / OTH;
+  auto fn = expand_dw_kernel<K, S, OTH, OTW>;
+  static bool ready = false;
+  if (!ready) {
+    TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+    ready = true;
+  }
+  TFIMM_LAUNCH(fn, dim3((unsigned)(a.tiles_x * tiles_y), (unsigned)B), dim3(G::NT), (size_t)G::LDS, st, a);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int tfimm_hip_expand_dwconv(const tfimm_expand_dw_desc* d, void* stream) {
+  if (!d) TFIMM_FAIL(TFIMM_EINVAL, "expand_dwconv: null descriptor");
+  if (!d->x || !d->w1 || !d->b1 || !d->wdw || !d->b2 || !d->y) TFIMM_FAIL(TFIMM_EINVAL, "expand_dwconv: null pointer");
+  if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->OH <= 0 || d->OW <= 0)
+    TFIMM_FAIL(TFIMM_EINVAL, "expand_dwconv: bad shape");
+  if (d->Cin <= 0 || (d->Cin & 7) || d->Cin > 32)
+    TFIMM_FAIL(TFIMM_EUNSUP, "expand_dwconv: Cin=%d (multiples of 8 up to 32)", d->Cin);
+  if ((d->C & 1) || d->Cpad != (d->C + 31) / 32 * 32)
+    TFIMM_FAIL(TFIMM_EINVAL, "expand_dwconv: C=%d must be even and Cpad=%d its multiple-of-32 ceiling", d->C, d->Cpad);
+  if (d->B > 65535) TFIMM_FAIL(TFIMM_EUNSUP, "expand_dwconv: batch %d > 65535", d->B);
+  if ((((uintptr_t)d->x | (uintptr_t)d->w1 | (uintptr_t)d->b1) & 15) || ((uintptr_t)d->y & 3))
+    TFIMM_FAIL(TFIMM_EINVAL, "expand_dwconv: x / w1 / b1 must be 16-byte aligned, y 4-byte aligned");
+  if (d->pad_t < 0 || d->pad_l < 0 || d->pad_t >= d->k || d->pad_l >= d->k)
+    TFIMM_FAIL(TFIMM_EINVAL, "expand_dwconv: padding (%d, %d) for k=%d", d->pad_t, d->pad_l, d->k);
+  if ((d->OH - 1) * d->stride - d->pad_t >= d->H || (d->OW - 1) * d->stride - d->pad_l >= d->W)
+    TFIMM_FAIL(TFIMM_EINVAL, "expand_dwconv: output %dx%d does not fit input %dx%d", d->OH, d->OW, d->H, d->W);
+  MbArgs a;
+  a.x = (const bf16_t*)d->x; a.w1 = (const uint4*)d->w1; a.b1 = d->b1; a.wdw = d->wdw; a.b2 = d->b2;
+  a.y = (bf16_t*)d->y; a.sums = d->sum_out;
+  a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.C = d->C; a.Cpad = d->Cpad; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
+  a.OH = d->OH; a.OW = d->OW; a.tiles_x = 0; a.act1 = d->act1; a.act2 = d->act2;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->k == 3 && d->stride == 1) return launch_expand_dw<3, 1, 12, 32>(a, d->B, st);
+  if (d->k == 3 && d->stride == 2) return launch_expand_dw<3, 2, 8, 16>(a, d->B, st);
+  if (d->k == 5 && d->stride == 1) return launch_expand_dw<5, 1, 8, 32>(a, d->B, st);
+  if (d->k == 5 && d->stride == 2) return launch_expand_dw<5, 2, 6, 16>(a, d->B, st);
+  TFIMM_FAIL(TFIMM_EUNSUP, "expand_dwconv: k=%d stride=%d (3 or 5, stride 1 or 2)", d->k, d->stride);
+}

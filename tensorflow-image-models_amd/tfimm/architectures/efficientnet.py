@@ -312,16 +312,25 @@ class EfficientNet(Model):
             p = blk.name
             shortcut = x if blk.skip else None
             if blk.type in ("ds", "ir"):
+                fused = None
                 if blk.type == "ir":
-                    x = b.conv(x, p + "/conv_pw/kernel", bn=p + "/bn1", bn_eps=eps, act=blk.act,
-                               cite="efficientnet_blocks.py:440-442")
                     dw_bn, proj, proj_bn, proj_act = p + "/bn2", p + "/conv_pwl/kernel", p + "/bn3", ""
+                    # narrow inputs (the first stages): expansion + depthwise as one launch, the expanded tensor stays in LDS
+                    fused = b.expand_dwconv(x, p + "/conv_pw/kernel", p + "/bn1", p + "/conv_dw/depthwise_kernel", dw_bn,
+                                            bn_eps=eps, stride=blk.stride, padding=pad(blk.k, blk.stride), act=blk.act,
+                                            squeeze=blk.rd > 0, cite="efficientnet_blocks.py:438-445")
+                    if fused is None:
+                        x = b.conv(x, p + "/conv_pw/kernel", bn=p + "/bn1", bn_eps=eps, act=blk.act,
+                                   cite="efficientnet_blocks.py:440-442")
                 else:
                     dw_bn, proj, proj_bn = p + "/bn1", p + "/conv_pw/kernel", p + "/bn2"
                     proj_act = blk.act if blk.pw_act else ""
-                x, sums = b.dwconv(x, p + "/conv_dw/depthwise_kernel", stride=blk.stride, padding=pad(blk.k, blk.stride),
-                                   bn=dw_bn, bn_eps=eps, act=blk.act, squeeze=blk.rd > 0,
-                                   cite="efficientnet_blocks.py:350-352,443-445")
+                if fused is not None:
+                    x, sums = fused
+                else:
+                    x, sums = b.dwconv(x, p + "/conv_dw/depthwise_kernel", stride=blk.stride, padding=pad(blk.k, blk.stride),
+                                       bn=dw_bn, bn_eps=eps, act=blk.act, squeeze=blk.rd > 0,
+                                       cite="efficientnet_blocks.py:350-352,443-445")
                 gate = None
                 if blk.rd:
                     gate = b.se_gate(sums, x.rows, p + "/se/conv_reduce/kernel", p + "/se/conv_reduce/bias",

@@ -79,6 +79,16 @@ class ChainDesc(C.Structure):
     ]
 
 
+class ExpandDwDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p), ("wdw", C.c_void_p), ("b2", C.c_void_p),
+        ("y", C.c_void_p), ("sum_out", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("C", C.c_int32), ("Cpad", C.c_int32),
+        ("k", C.c_int32), ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32), ("OH", C.c_int32),
+        ("OW", C.c_int32), ("act1", C.c_int32), ("act2", C.c_int32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol declared in include/tfimm_hip.h
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SYMBOLS = {
@@ -87,6 +97,7 @@ SYMBOLS = {
     "tfimm_hip_device_info": (_i, [_i, C.c_char_p, _i]),
     "tfimm_hip_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "tfimm_hip_conv_chain": (_i, [C.POINTER(ChainDesc), _vp]),
+    "tfimm_hip_expand_dwconv": (_i, [C.POINTER(ExpandDwDesc), _vp]),
     "tfimm_hip_stem_conv_pool": (_i, [C.POINTER(StemDesc), _vp]),
     "tfimm_hip_cast_input": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp]),
     "tfimm_hip_cast_input_pad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

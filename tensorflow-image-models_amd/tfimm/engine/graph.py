@@ -116,7 +116,7 @@ class Program:
                 total += a["flops"]
             elif op.kind == "dwconv":
                 total += 2 * a["OH"] * a["OW"] * a["C"] * a["k"] * a["k"]
-            elif op.kind == "grouped_conv":
+            elif op.kind in ("grouped_conv", "expand_dwconv"):
                 total += a["flops"]
         return total
 
@@ -617,6 +617,48 @@ class Builder:
               sums=None if sums is None else sums.id)
         return out, sums
 
+    def expand_dwconv(self, x: TRef, pw_kernel: str, pw_bn: str, dw_kernel: str, dw_bn: str, *, bn_eps=1e-5, stride=1,
+                      padding="same", act="", squeeze=False, cite=""):
+        """Pointwise expansion (1x1 Conv2D + BN + act) followed by DepthwiseConv2D + BN + act as ONE launch
+        (tfimm_hip_expand_dwconv): the expanded tensor of an inverted-residual block stays in LDS.  Returns None when the
+        shape is outside what that kernel is built for (the caller lowers a GEMM and a depthwise launch); otherwise
+        (output, squeeze sums or None) like ``dwconv``."""
+        p = self.p
+        k1, kd = self.wget(pw_kernel), self.wget(dw_kernel)
+        cin, c = k1.shape[2], k1.shape[3]
+        kh, kw = kd.shape[:2]
+        if (k1.shape[:2] != (1, 1) or x.C != cin or cin % 8 or cin > 32 or c % 2 or kd.shape[2:] != (c, 1) or kh != kw
+                or (kh, stride) not in ((3, 1), (3, 2), (5, 2)) or os.environ.get("TFIMM_NO_MBCONV_FUSION", "0") == "1"):
+            return None
+        if padding == "same":
+            OH, pt, _ = same_padding(x.H, kh, stride)
+            OW, pl, _ = same_padding(x.W, kw, stride)
+        else:
+            pt = pl = int(padding)
+            OH = (x.H + 2 * pt - kh) // stride + 1
+            OW = (x.W + 2 * pl - kw) // stride + 1
+        if pt >= kh or pl >= kh or OH <= 0 or OW <= 0:
+            return None
+        cpad = pack.ceil_to(c, 32)
+        s1, t1 = self.bn(pw_bn, bn_eps)
+        s2, t2 = self.bn(dw_bn, bn_eps)
+        w1 = pack.pack_expand_frag(k1.reshape(cin, c).astype(np.float32) * s1.reshape(1, c), cpad)
+        wd, b2 = pack.pack_depthwise(kd, s2, t2)
+
+        def padc(a):
+            out = np.zeros(a.shape[:-1] + (cpad,), np.float32)
+            out[..., :c] = a
+            return out
+        consts = {"w1": p.new_const(w1, pw_kernel + ":frag"), "b1": p.new_const(padc(np.asarray(t1, np.float32)), pw_kernel + ":bias"),
+                  "wdw": p.new_const(padc(wd), dw_kernel + ":pad"), "b2": p.new_const(padc(b2), dw_kernel + ":bias")}
+        out = p.new_tensor(OH * OW, c, OH, OW, name=dw_kernel)
+        sums = p.new_tensor(1, c, dtype="f32", name=dw_kernel + ":sums") if squeeze else None
+        p.add("expand_dwconv", [x], out, consts, cite=cite, extra_outputs=[sums] if sums is not None else [],
+              H=x.H, W=x.W, Cin=cin, C=c, Cpad=cpad, k=kh, stride=stride, pad_t=pt, pad_l=pl, OH=OH, OW=OW, act=act,
+              sums=None if sums is None else sums.id,
+              flops=2 * x.H * x.W * cin * c + 2 * OH * OW * c * kh * kw)
+        return out, sums
+
     def se_gate(self, sums: TRef, count: int, w_reduce: str, b_reduce: str, w_expand: str, b_expand: str,
                 act: str, gate_act="sigmoid", cite="") -> TRef:
         p = self.p
@@ -822,6 +864,20 @@ class Plan:
                 d.act1, d.act2 = ffi.ACT[a["act1"]], ffi.ACT[a["act2"]]
                 self._keepalive.append(d)
                 self.calls.append((lib.tfimm_hip_conv_chain, (C.byref(d),)))
+            elif k == "expand_dwconv":
+                d = ffi.ExpandDwDesc()
+                d.x, d.y = self.tptr(op.inputs[0]), self.tptr(op.output)
+                d.w1, d.b1 = self.cptr(op.consts["w1"]), self.cptr(op.consts["b1"])
+                d.wdw, d.b2 = self.cptr(op.consts["wdw"]), self.cptr(op.consts["b2"])
+                d.sum_out = None
+                if a["sums"] is not None:
+                    d.sum_out = self.tptr(a["sums"])
+                    self.calls.append(("memset", (d.sum_out, B * a["C"] * 4)))
+                d.B, d.H, d.W, d.Cin, d.C, d.Cpad = B, a["H"], a["W"], a["Cin"], a["C"], a["Cpad"]
+                d.k, d.stride, d.pad_t, d.pad_l, d.OH, d.OW = a["k"], a["stride"], a["pad_t"], a["pad_l"], a["OH"], a["OW"]
+                d.act1 = d.act2 = ffi.ACT[a["act"]]
+                self._keepalive.append(d)
+                self.calls.append((lib.tfimm_hip_expand_dwconv, (C.byref(d),)))
             elif k == "grouped_conv":
                 self.calls.append((lib.tfimm_hip_grouped_conv3x3,
                                    (self.tptr(op.inputs[0]), self.cptr(op.consts["w"]), self.cptr(op.consts["bias"]),

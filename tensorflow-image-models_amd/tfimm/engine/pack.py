@@ -156,3 +156,17 @@ def pack_grouped3x3(kernel: np.ndarray, groups: int, scale: Optional[np.ndarray]
             cl = half * 16 + (lane >> 5)[:, None] * 8 + np.arange(8)[None, :]      # (64, 8)
             out[:, tap * 2 + half] = dense[:, tap][:, (lane & 31)[:, None], cl]
     return to_bf16_bits(out).reshape(nsg, 18, 64, 8)
+
+
+def pack_expand_frag(w1: np.ndarray, cpad: int) -> np.ndarray:
+    """Expand (1x1) weights ``w1[Cin][C]`` (BN scale folded, Cin <= 32) as the MFMA A fragments
+    tfimm_hip_expand_dwconv loads: uint16 [cpad/32][2][64][8], element [cc][ks][lane][j] =
+    w1[16 ks + 8 (lane >> 5) + j][32 cc + (lane & 31)], zero beyond Cin / C."""
+    cin, c = w1.shape
+    assert cin <= 32 and cpad % 32 == 0 and cpad >= c
+    full = np.zeros((32, cpad), np.float32)
+    full[:cin, :c] = w1
+    lane = np.arange(64)
+    k = (16 * np.arange(2)[:, None, None] + 8 * (lane >> 5)[None, :, None] + np.arange(8)[None, None, :])    # [2][64][8]
+    ch = 32 * np.arange(cpad // 32)[:, None, None, None] + (lane & 31)[None, None, :, None]                # [cc][1][64][1]
+    return to_bf16_bits(full[k[None], ch])

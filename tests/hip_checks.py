@@ -705,6 +705,56 @@ CASES["dwconv_k5_s2_same_95_c192"] = lambda: _dw_case(2, 95, 95, 192, 5, 2, "sam
 CASES["dwconv_k3_p1_generic_c6"] = lambda: _dw_case(2, 8, 8, 6, 3, 1, 1, "relu", 95)
 
 
+def _expand_dw_case(B, H, W, cin, c, k, stride, padding, act, seed, squeeze=True):
+    """tfimm_hip_expand_dwconv against 1x1 conv + act (rounded to bf16, as the two-launch path stores it) + depthwise + act"""
+    import hip_ops as Hh
+    r = _rng(seed)
+    x = _bf(r.standard_normal((B, H, W, cin)))
+    k1 = (r.standard_normal((cin, c)) / np.sqrt(cin)).astype(np.float32)
+    s1, t1 = r.uniform(0.5, 1.5, c).astype(np.float32), (0.5 * r.standard_normal(c)).astype(np.float32)
+    kd = (r.standard_normal((k, k, c, 1)) / k).astype(np.float32)
+    s2, t2 = r.uniform(0.5, 1.5, c).astype(np.float32), (0.5 * r.standard_normal(c)).astype(np.float32)
+    cpad = pack.ceil_to(c, 32)
+    w1s = _bf(k1 * s1.reshape(1, c))                        # the kernel multiplies bf16 weights
+    frag = pack.pack_expand_frag(k1 * s1.reshape(1, c), cpad)
+    wd, b2 = pack.pack_depthwise(kd, s2, t2)
+
+    def padc(a):
+        out = np.zeros(a.shape[:-1] + (cpad,), np.float32)
+        out[..., :c] = a
+        return out
+    e = O.activation(torch.from_numpy(x.reshape(-1, cin).astype(np.float64) @ w1s.astype(np.float64)).float()
+                     + torch.from_numpy(t1), act)
+    e = torch.from_numpy(_bf(e.numpy())).reshape(B, H, W, c)
+    kf = torch.from_numpy(kd * s2.reshape(1, 1, -1, 1))
+    if padding == "same":
+        y = O.depthwise_conv2d(e, kf, None, stride, "same")
+        pt, _ = O.same_pad_amounts(H, k, stride)
+        pl, _ = O.same_pad_amounts(W, k, stride)
+    else:
+        y = O.depthwise_conv2d(O.zero_pad2d(e, padding), kf, None, stride)
+        pt = pl = padding
+    y = O.activation(y + torch.from_numpy(t2), act)
+    OH, OW = y.shape[1], y.shape[2]
+    got, sums = Hh.expand_dwconv(Hh.dev_bf16(x), Hh.dev_bits(frag), Hh.dev_f32(padc(t1)),
+                                 Hh.dev_f32(padc(wd)), Hh.dev_f32(padc(b2)), c, k, stride, pt, pl, OH, OW, act=act,
+                                 want_sums=squeeze)
+    Hh.sync()
+    err = _err(_cpu(got), y.numpy())
+    if squeeze:
+        err = max(err, _err(_cpu(sums), _cpu(got).sum((1, 2))) / 10)      # sums are of the stored bf16 outputs
+    return err, TOL_BF16
+
+
+CASES["expand_dw_k3_s1_24_144_odd"] = lambda: _expand_dw_case(2, 19, 37, 24, 144, 3, 1, "same", "swish", 300)
+CASES["expand_dw_k3_s2_even_to_odd"] = lambda: _expand_dw_case(2, 38, 30, 24, 144, 3, 2, "same", "swish", 301)
+CASES["expand_dw_k3_s1_32_192_tiles"] = lambda: _expand_dw_case(3, 47, 70, 32, 192, 3, 1, "same", "swish", 302)    # 4 x 3 tiles, ragged edges
+CASES["expand_dw_k5_s2_32_192"] = lambda: _expand_dw_case(2, 31, 45, 32, 192, 5, 2, "same", "swish", 303)
+CASES["expand_dw_k3_s2_p1_relu6_16_96"] = lambda: _expand_dw_case(2, 28, 28, 16, 96, 3, 2, 1, "relu6", 304, squeeze=False)   # MobileNet-V2 style
+CASES["expand_dw_k3_s1_8_40_partial_chunk"] = lambda: _expand_dw_case(2, 9, 9, 8, 40, 3, 1, "same", "swish", 305)    # C = 32 + 8
+CASES["expand_dw_k5_s2_tiny_image"] = lambda: _expand_dw_case(1, 5, 4, 24, 48, 5, 2, "same", "swish", 306)      # image smaller than one tile
+
+
 def _se_case(B, R, Cc, rd, seed):
     import hip_ops as H
     r = _rng(seed)

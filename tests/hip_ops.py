@@ -214,6 +214,19 @@ def dwconv(x, w, bias, k, stride, pad_t, pad_l, OH, OW, act="", want_sums=False)
     return out, sums
 
 
+def expand_dwconv(x, w1frag, b1, wdw, b2, Cexp, k, stride, pad_t, pad_l, OH, OW, act="", want_sums=False):
+    B, H, W, Cin = x.shape
+    out = torch.empty(B, OH, OW, Cexp, dtype=torch.bfloat16, device=DEV)
+    sums = torch.zeros(B, Cexp, dtype=torch.float32, device=DEV) if want_sums else None
+    d = ffi.ExpandDwDesc()
+    d.x, d.w1, d.b1, d.wdw, d.b2, d.y, d.sum_out = ptr(x), ptr(w1frag), ptr(b1), ptr(wdw), ptr(b2), ptr(out), ptr(sums)
+    d.B, d.H, d.W, d.Cin, d.C, d.Cpad = B, H, W, Cin, Cexp, b1.numel()
+    d.k, d.stride, d.pad_t, d.pad_l, d.OH, d.OW = k, stride, pad_t, pad_l, OH, OW
+    d.act1 = d.act2 = ffi.ACT[act]
+    ffi.check(lib.tfimm_hip_expand_dwconv(C.byref(d), stream()), "expand_dwconv")
+    return out, sums
+
+
 def se_gate(sums, inv_count, w1, b1, w2, b2, act, gate_act="sigmoid"):
     B, Cc = sums.shape
     rd = w1.shape[0]

@@ -174,3 +174,21 @@ def test_programs_of_one_model_share_their_packed_constants():
     assert all(a is b for a, b in zip(p1._dev_consts, p3._dev_consts))
     m.set_weights(synthetic_weights(m, 5))
     assert not m._const_cache
+
+
+def test_narrow_mbconv_fronts_are_one_launch(monkeypatch):
+    """expansion 1x1 + depthwise of the inverted-residual blocks whose input has at most 32 channels lower to
+    tfimm_hip_expand_dwconv (the expanded tensor never reaches HBM); FLOP count and the following squeeze-excite are unchanged;
+    TFIMM_NO_MBCONV_FUSION=1 keeps the GEMM + depthwise pair"""
+    kinds, prog = _kinds("efficientnet_b0")
+    fused = [op for op in prog.ops if op.kind == "expand_dwconv"]
+    assert [(op.attrs["Cin"], op.attrs["C"], op.attrs["k"], op.attrs["stride"], op.attrs["H"]) for op in fused] == \
+        [(16, 96, 3, 2, 112), (24, 144, 3, 1, 56), (24, 144, 5, 2, 56)]
+    assert all(op.attrs["sums"] is not None and op.attrs["Cpad"] % 32 == 0 for op in fused)
+    for op in fused:       # TF "same" padding of the EXPANDED tensor: nothing on top / left at stride 2 on even sizes
+        assert (op.attrs["pad_t"], op.attrs["pad_l"]) == ((1, 1) if op.attrs["stride"] == 1 else
+                                                          ((op.attrs["k"] - 2) // 2,) * 2)
+    flops = prog.flops_per_image()
+    monkeypatch.setenv("TFIMM_NO_MBCONV_FUSION", "1")
+    kinds2, prog2 = _kinds("efficientnet_b0")
+    assert "expand_dwconv" not in kinds2 and len(kinds2) == len(kinds) + 3 and prog2.flops_per_image() == flops

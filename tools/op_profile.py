@@ -50,6 +50,9 @@ def op_bytes_flops(op, prog, B):
     if k == "dwconv":
         byts = B * (a["H"] * a["W"] + a["OH"] * a["OW"]) * a["C"] * 2
         return byts, 2.0 * B * a["OH"] * a["OW"] * a["C"] * a["k"] ** 2, f"C={a['C']} k={a['k']} s={a['stride']} {a['H']}->{a['OH']}"
+    if k == "expand_dwconv":
+        byts = B * (a["H"] * a["W"] * a["Cin"] + a["OH"] * a["OW"] * a["C"]) * 2
+        return byts, float(a["flops"]) * B, f"{a['Cin']}->{a['C']} k={a['k']} s={a['stride']} {a['H']}->{a['OH']} (fused expand + dw)"
     byts = sum(t.bytes_per_image for t in tin if t.dtype != "raw") * B
     if tout is not None:
         byts += tout.bytes_per_image * B
