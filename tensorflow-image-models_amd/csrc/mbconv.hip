@@ -20,6 +20,7 @@
 //   Both phases are VALU-bound (the activation: two quarter-rate transcendentals per value for swish); two workgroups share a
 //   CU so one's global loads / stores sit under the other's arithmetic.  HBM traffic: input halo once + output once.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -32,6 +33,7 @@ struct MbArgs {
   bf16_t* y;
   float* sums;
   int H, W, Cin, C, Cpad, pad_t, pad_l, OH, OW, tiles_x, act1, act2;
+  int dbg;      // TFIMM_MB_DBG ablation bits: 1 no output stores, 2 no phase-2 activation, 4 no phase-1 activation
 };
 
 template <int K, int S, int OTH, int OTW>
@@ -49,7 +51,9 @@ struct MbGeom {
   static_assert(LDS <= 80 * 1024, "two workgroups per CU");
 };
 
-template <int K, int S, int OTH, int OTW>
+// ACT >= 0: both activations are that TFIMM_ACT_* (its parameters fold into the instructions: no scalar registers, no class
+// branches); ACT < 0: read act1 / act2 from the arguments
+template <int K, int S, int OTH, int OTW, int ACT>
 __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
   using G = MbGeom<K, S, OTH, OTW>;
   extern __shared__ __attribute__((aligned(16))) unsigned char mb_smem[];
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
     const bool ok = px < G::NPX && (unsigned)(gy0 + iy) < (unsigned)p.H && (unsigned)(gx0 + ix) < (unsigned)p.W;
     vbits |= (ok ? 1u : 0u) << j;
   }
-  const ActParams a1 = make_act(p.act1), a2 = make_act(p.act2);
+  const ActParams a1 = make_act(ACT >= 0 ? ACT : p.act1), a2 = make_act(ACT >= 0 ? ACT : p.act2);
   const int nchunks = p.Cpad >> 5;
   // phase-2 role of this thread
   const int cp = tid & 15, slot = tid >> 4, col = slot % OTW, rg = slot / OTW;
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
               const int q = 2 * h + (e >> 1), r = (e & 1) * 2;
               v[e] = tfimm_f32x2{acc[q * 4 + r] + bq[q][r], acc[q * 4 + r + 1] + bq[q][r + 1]};
             }
-            act8p(v, a1);
+            if (!(p.dbg & 4)) act8p(v, a1);
             if (px < G::NPX) {
 #pragma unroll
               for (int qq = 0; qq < 2; ++qq) {
@@ -202,13 +206,13 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
         tfimm_f32x2 v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (r0 + e < G::RPT) ? acc[(r0 + e < G::RPT) ? r0 + e : 0] : tfimm_f32x2{0.f, 0.f};
-        act8p(v, a2);
+        if (!(p.dbg & 2)) act8p(v, a2);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (r0 + e < G::RPT) {
             const uint32_t pk = pack_bf2(v[e][0], v[e][1]);
             if (cok && oyb + r0 + e < p.OH) {
-              *reinterpret_cast<uint32_t*>(yb + (size_t)(r0 + e) * p.OW * p.C) = pk;
+              if (!(p.dbg & 1)) *reinterpret_cast<uint32_t*>(yb + (size_t)(r0 + e) * p.OW * p.C) = pk;
               // the squeeze sees the stored (bf16-rounded) activations, as in tfimm_hip_dwconv
               tot += tfimm_f32x2{__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)};
             }
@@ -229,13 +233,13 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
   }
 }
 
-template <int K, int S, int OTH, int OTW>
-int launch_expand_dw(const MbArgs& a0, int B, hipStream_t st) {
+template <int K, int S, int OTH, int OTW, int ACT>
+int launch_expand_dw_act(const MbArgs& a0, int B, hipStream_t st) {
   using G = MbGeom<K, S, OTH, OTW>;
   MbArgs a = a0;
   a.tiles_x = (a.OW + OTW - 1) / OTW;
   const int tiles_y = (a.OH + OTH - 1) / OTH;
-  auto fn = expand_dw_kernel<K, S, OTH, OTW>;
+  auto fn = expand_dw_kernel<K, S, OTH, OTW, ACT>;
   static bool ready = false;
   if (!ready) {
     TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
@@ -243,6 +247,13 @@ int launch_expand_dw(const MbArgs& a0, int B, hipStream_t st) {
   }
   TFIMM_LAUNCH(fn, dim3((unsigned)(a.tiles_x * tiles_y), (unsigned)B), dim3(G::NT), (size_t)G::LDS, st, a);
   return 0;
+}
+
+template <int K, int S, int OTH, int OTW>
+int launch_expand_dw(const MbArgs& a, int B, hipStream_t st) {
+  if (a.act1 == a.act2 && a.act1 == TFIMM_ACT_SWISH) return launch_expand_dw_act<K, S, OTH, OTW, TFIMM_ACT_SWISH>(a, B, st);
+  if (a.act1 == a.act2 && a.act1 == TFIMM_ACT_RELU6) return launch_expand_dw_act<K, S, OTH, OTW, TFIMM_ACT_RELU6>(a, B, st);
+  return launch_expand_dw_act<K, S, OTH, OTW, -1>(a, B, st);
 }
 
 }  // namespace
@@ -268,10 +279,11 @@ extern "C" int tfimm_hip_expand_dwconv(const tfimm_expand_dw_desc* d, void* stre
   a.y = (bf16_t*)d->y; a.sums = d->sum_out;
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.C = d->C; a.Cpad = d->Cpad; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
   a.OH = d->OH; a.OW = d->OW; a.tiles_x = 0; a.act1 = d->act1; a.act2 = d->act2;
+  static const int dbg = getenv("TFIMM_MB_DBG") ? atoi(getenv("TFIMM_MB_DBG")) : 0;
+  a.dbg = dbg;
   hipStream_t st = (hipStream_t)stream;
   if (d->k == 3 && d->stride == 1) return launch_expand_dw<3, 1, 12, 32>(a, d->B, st);
   if (d->k == 3 && d->stride == 2) return launch_expand_dw<3, 2, 8, 16>(a, d->B, st);
-  if (d->k == 5 && d->stride == 1) return launch_expand_dw<5, 1, 8, 32>(a, d->B, st);
   if (d->k == 5 && d->stride == 2) return launch_expand_dw<5, 2, 6, 16>(a, d->B, st);
   TFIMM_FAIL(TFIMM_EUNSUP, "expand_dwconv: k=%d stride=%d (3 or 5, stride 1 or 2)", d->k, d->stride);
 }

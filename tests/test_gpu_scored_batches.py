@@ -5,7 +5,7 @@ shapes are picked and > 2 GiB tensors are chunked -- none of which the B = 1..2 
 configuration: (i) rows of the big-batch logits equal the B = 2 forward of the same images (bit for bit where every
 reduction has a fixed order; EfficientNet's SE squeeze accumulates per-channel sums with fp32 atomics whose order
 changes from launch to launch -- 1e-7-level gate differences flip bf16 roundings further down, so that model gets a band
-of 1e-2 of the largest logit, about two bf16 ulps, and its run-to-run spread at the same batch must sit inside the same
+of 2e-2 of the largest logit, a few bf16 ulps, and its run-to-run spread at the same batch must sit inside the same
 band), and
 (ii) a 16-image subset meets the usual bar against the fp32 oracle."""
 import numpy as np
@@ -19,7 +19,7 @@ from tfimm.utils.init import synthetic_weights
 
 pytestmark = pytest.mark.gpu
 
-ATOMIC_BAND = 1e-2
+ATOMIC_BAND = 2e-2        # max over 256 x 1000 logits; observed 0.5e-2 .. 1.1e-2 between two runs of the same plan
 SCORED = [("resnet50", 256, True), ("vit_base_patch16_224", 512, True), ("swin_base_patch4_window7_224", 256, True),
           ("efficientnet_b4", 256, False)]
 
