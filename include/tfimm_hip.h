@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TFIMM_HIP_ABI_VERSION 1
+#define TFIMM_HIP_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define TFIMM_API __attribute__((visibility("default")))
@@ -114,6 +114,11 @@ typedef struct tfimm_gemm_desc {
                              Lets a stride-2 RGB stem / patch embedding run on the pixel-PAIR view of a
                              zero-padded 4-channel image ([B][Hp][Wp/2][8], see tfimm_hip_cast_input_pad):
                              vertical stride s, horizontal stride s/2, kernel width ceil(KW/2). */
+  int32_t pix_pitch;      /* TFIMM_A_CONV only: elements between consecutive pixels of x if it differs from Cin
+                             (0 = Cin).  With `a` pointing at channel c0 of a [B][H][W][C] tensor, Cin = w and
+                             pix_pitch = C the convolution reads the channel slice [c0, c0 + w) -- one group of a
+                             grouped convolution (resnet.py:229-236); ldc / the `out` pointer place its w output
+                             channels the same way. */
 } tfimm_gemm_desc;
 
 TFIMM_API int tfimm_hip_gemm(const tfimm_gemm_desc* d, void* stream);

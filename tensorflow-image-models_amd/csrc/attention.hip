@@ -35,6 +35,7 @@ struct AttnArgs {
   int ld;       // 3 * heads * hd
   int dmodel;   // heads * hd
   int dbg;      // TFIMM_ATTN_DBG (profiling only): 1 skip the key loop, 2 skip K/V staging
+  int xcd_map;  // resident kernel: XCD-contiguous (sequence, head) ranges (TFIMM_ATTN_XCD=0 switches it off)
 };
 
 template <bool SWIN>
@@ -291,8 +292,16 @@ __global__ void __launch_bounds__(NW * 64) attn_resident_kernel(const AttnArgs p
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int h = blockIdx.x % p.heads;
-  const int seq = blockIdx.x / p.heads;
+  // Workgroups are dealt to the 8 XCDs round-robin; the heads of one sequence read 64 / 128-byte slices of the SAME token
+  // rows (Swin: two or four heads per 128-byte line), so consecutive (sequence, head) items go to ONE XCD -- each XCD owns
+  // a contiguous range of items and a row is pulled through one L2 instead of up to eight.
+  int item = blockIdx.x;
+  if (p.xcd_map) {
+    const int G = (int)gridDim.x, xcd = item & 7, idx = item >> 3;
+    item = xcd * (G >> 3) + min(xcd, G & 7) + idx;
+  }
+  const int h = item % p.heads;
+  const int seq = item / p.heads;
 
   // ---- Swin: global row (and region id) of every token of this window, once per workgroup -- the
   //      roll / window_partition index map costs several integer divisions per token
@@ -829,6 +838,8 @@ extern "C" int tfimm_hip_attention(const tfimm_attn_desc* dp, void* stream) {
   a.dmodel = d.heads * d.hd; a.ld = 3 * a.dmodel;
   static const int attn_dbg = getenv("TFIMM_ATTN_DBG") ? atoi(getenv("TFIMM_ATTN_DBG")) : 0;
   a.dbg = attn_dbg;
+  static const int attn_xcd = getenv("TFIMM_ATTN_XCD") ? atoi(getenv("TFIMM_ATTN_XCD")) : 1;
+  a.xcd_map = attn_xcd;
   int64_t nseq;
   if (d.window > 0) {
     if (d.res_h <= 0 || d.res_w <= 0 || d.res_h % d.window || d.res_w % d.window ||

@@ -197,6 +197,7 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
   g.KWp = (d.KW + 1) & ~1;
   g.stride = d.stride; g.pad_t = d.pad_t; g.pad_l = d.pad_l; g.OH = d.OH; g.OW = d.OW;
   g.stride_w = d.stride_w > 0 ? d.stride_w : d.stride;
+  g.cpitch = d.pix_pitch > 0 ? d.pix_pitch : d.Cin;
   g.rows_per_image = d.rows_per_image;
 
   int kmode;
@@ -218,9 +219,11 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
     if (((uintptr_t)d.a & 15)) TFIMM_FAIL(TFIMM_EINVAL, "gemm: conv input must be 16-byte aligned");
     if (d.mode == TFIMM_A_CONV) {
       if (d.K != d.KH * d.KW * d.Cin) TFIMM_FAIL(TFIMM_EINVAL, "gemm: K != KH*KW*Cin");
-      kmode = (d.Cin & 7) ? K_CONV_SCALAR : K_CONV;  // odd channel counts: element loads
+      if (d.pix_pitch < 0 || (d.pix_pitch > 0 && d.pix_pitch < d.Cin))
+        TFIMM_FAIL(TFIMM_EINVAL, "gemm: pix_pitch=%d < Cin=%d", d.pix_pitch, d.Cin);
+      kmode = ((d.Cin | g.cpitch) & 7) ? K_CONV_SCALAR : K_CONV;  // odd channel counts: element loads
     } else {
-      if (d.Cin != 4) TFIMM_FAIL(TFIMM_EINVAL, "gemm: C4 mode needs Cin == 4");
+      if (d.Cin != 4 || d.pix_pitch > 4) TFIMM_FAIL(TFIMM_EINVAL, "gemm: C4 mode needs Cin == 4 (and no pixel pitch)");
       if (d.K != d.KH * g.KWp * 4) TFIMM_FAIL(TFIMM_EINVAL, "gemm: K != KH*KWp*4 (K=%d)", d.K);
       kmode = K_CONV_C4;
     }
@@ -236,7 +239,7 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
   // ---- persistent LDS-DMA family (default): same operand requirements as the DMA family below
   {
     const int64_t a_bytes = (d.mode == TFIMM_A_DENSE) ? ((int64_t)(d.M - 1) * d.lda + d.K) * 2
-                                                       : (int64_t)d.B * d.H * d.W * d.Cin * 2;
+                                                       : (((int64_t)d.B * d.H * d.W - 1) * g.cpitch + d.Cin) * 2;
     const int64_t w_bytes = (int64_t)d.N * d.ldw * 2;
     const bool hinted_other = d.tile_hint > 0 && d.tile_hint <= 20 && g.stride_w == g.stride;
     // extents of the output / residual buffers as the epilogue addresses them (row remap included)
@@ -341,7 +344,7 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
   //      tensors addressable with a 31-bit byte offset
   {
     const int64_t a_bytes = (d.mode == TFIMM_A_DENSE) ? ((int64_t)(d.M - 1) * d.lda + d.K) * 2
-                                                       : (int64_t)d.B * d.H * d.W * d.Cin * 2;
+                                                       : (((int64_t)d.B * d.H * d.W - 1) * g.cpitch + d.Cin) * 2;
     const int64_t w_bytes = (int64_t)d.N * d.ldw * 2;
     const bool hint_v1 = d.tile_hint > 0 && d.tile_hint <= TFIMM_GEMM_NUM_TILES;  // 11..16 = this family
     const bool ok = (kmode == K_DENSE || kmode == K_CONV) && !hint_v1 && !dma_disabled() &&

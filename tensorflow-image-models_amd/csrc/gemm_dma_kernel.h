@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_dma_kernel(const G
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
         const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
         const bool ok = kg < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const unsigned off = ok ? (unsigned)((((size_t)(a_pix[j] + iy * p.W + ix)) * p.Cin + ci) * 2) : kOobOffset;
+        const unsigned off = ok ? (unsigned)((((size_t)(a_pix[j] + iy * p.W + ix)) * p.cpitch + ci) * 2) : kOobOffset;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sa + (wave * A_INSTR + j) * 1024), 16,
                                                  (int)off, 0, 0, 0);
       }

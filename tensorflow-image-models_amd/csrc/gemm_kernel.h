@@ -53,6 +53,7 @@ struct GemmArgs {
   int remap_in, remap_out, remap_off;
   int B, H, W, Cin, KH, KW, KWp, stride, pad_t, pad_l, OH, OW;
   int stride_w;   // horizontal stride (== stride unless the pixel-pair view of an RGB stem is used)
+  int cpitch;     // elements between consecutive pixels of the conv input (Cin unless a channel slice is convolved)
   int rows_per_image;
   int res_vec;    // residual rows can be read as aligned 8-byte quads
   int out_vec;    // output rows can be written as aligned quads
@@ -197,7 +198,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_kernel(const GemmA
       for (int i = 0; i < A_ITERS; ++i) {
         const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
         const bool ok = kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const size_t off = ok ? ((size_t)(a_pix[i] + iy * p.W + ix)) * p.Cin + ci : (size_t)0;
+        const size_t off = ok ? ((size_t)(a_pix[i] + iy * p.W + ix)) * p.cpitch + ci : (size_t)0;
         ra[i] = *reinterpret_cast<const uint4*>(p.a + off);
       }
     } else if (KMODE == K_CONV_SCALAR) {
@@ -212,7 +213,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_kernel(const GemmA
           const int ky = tap / p.KW, kx = tap - ky * p.KW;
           const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
           const bool ok = k < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-          const size_t off = ok ? ((size_t)(a_pix[i] + iy * p.W + ix)) * p.Cin + ci : (size_t)0;
+          const size_t off = ok ? ((size_t)(a_pix[i] + iy * p.W + ix)) * p.cpitch + ci : (size_t)0;
           uint32_t v = (uint32_t)p.a[off];
           v = ok ? v : 0u;
           w[e >> 1] |= v << ((e & 1) * 16);

@@ -297,16 +297,21 @@ class ResNet(Model):
                     # (tfimm_hip_grouped_conv3x3) when a group has at most 32 channels
                     grouped = b.grouped_conv3x3(y, k2, c.cardinality, stride=cstride, bn=p + "/bn2", bn_eps=eps, act=act,
                                                 cite="resnet.py:229-241,273-276")
+                if c.cardinality > 1 and grouped is None and not gn:
+                    # groups of 64+ channels (ResNeXt-101 32x16d / 32d / 48d, the late stages of 32x8d): one implicit-GEMM
+                    # launch per group on its channel slice
+                    grouped = b.grouped_conv_split(y, k2, c.cardinality, stride=cstride, padding=1, bn=p + "/bn2", bn_eps=eps,
+                                                   act=act, cite="resnet.py:229-241,273-276")
                 if c.cardinality > 1 and grouped is None:
-                    # wider groups: a dense convolution over the block-diagonal expansion of the kernel -- exact (the
-                    # extra products are x * 0), at cardinality x the multiply-accumulates and weight bytes
+                    # what is left (group widths that are not multiples of 8, GroupNorm variants): a dense convolution over
+                    # the block-diagonal expansion of the kernel -- exact (the extra products are x * 0), at cardinality x the
+                    # multiply-accumulates and weight bytes
                     kg = b.wget(k2)
                     dense_bytes = 9 * kg.shape[3] * kg.shape[3] * 2
                     if dense_bytes > _DENSE_GROUPED_LIMIT:
                         raise NotImplementedError(
                             f"{c.name}: grouped 3x3 with {kg.shape[2]} channels per group would expand to a "
-                            f"{dense_bytes / 2**20:.0f} MiB dense kernel per block (limit {_DENSE_GROUPED_LIMIT / 2**20:.0f} MiB); "
-                            "tfimm_hip_grouped_conv3x3 covers groups of at most 32 channels")
+                            f"{dense_bytes / 2**20:.0f} MiB dense kernel per block (limit {_DENSE_GROUPED_LIMIT / 2**20:.0f} MiB)")
                     k2 = b.define(k2 + ":dense", _expand_grouped_kernel(kg, c.cardinality))
                     kw2["flops_k"] = 9 * y.C // c.cardinality
                 fused = None

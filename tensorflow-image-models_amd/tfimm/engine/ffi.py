@@ -36,6 +36,7 @@ class GemmDesc(C.Structure):
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32),
         ("pad_t", C.c_int32), ("pad_l", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32),
         ("rows_per_image", C.c_int32), ("tile_hint", C.c_int32), ("stride_w", C.c_int32),
+        ("pix_pitch", C.c_int32),
     ]
 
 
@@ -142,7 +143,7 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the ABI drifted
         fn.restype = res
         fn.argtypes = args
-    if lib.tfimm_hip_abi_version() != 1:
+    if lib.tfimm_hip_abi_version() != 2:
         raise ImportError("libtfimm_hip.so ABI version mismatch")
     return lib
 

@@ -399,6 +399,37 @@ class Builder:
               flops=2 * OH * OW * c * 9 * w)
         return out
 
+    def grouped_conv_split(self, x: TRef, kernel: str, groups: int, *, stride=1, padding=1, bn: Optional[str] = None,
+                           bn_eps=1e-5, act="", cite="") -> Optional[TRef]:
+        """Conv2D(groups) with wide groups as ONE tfimm_hip_gemm launch PER GROUP: the implicit-GEMM gather reads the
+        group's channel slice in place (``pix_pitch`` = the tensor's channel count, ``a`` offset to the slice) and writes its
+        output channels into their slice of the result (``ldc``, ``out_col``) -- no block-diagonal expansion, no channel
+        shuffle passes.  Needs group widths that are multiples of 8 (16-byte slices)."""
+        p = self.p
+        k = self.wget(kernel)
+        kh, kw, w, c = k.shape
+        if c % groups or x.C != w * groups or w % 8 or (c // groups) % 8:
+            return None
+        wo = c // groups
+        pad = int(padding)
+        OH = (x.H + 2 * pad - kh) // stride + 1
+        OW = (x.W + 2 * pad - kw) // stride + 1
+        scale = shift = None
+        if bn is not None:
+            scale, shift = self.bn(bn, bn_eps)
+        out = p.new_tensor(OH * OW, c, OH, OW, name=kernel)
+        for g in range(groups):
+            sl = slice(g * wo, (g + 1) * wo)
+            wt, bvec, kk, mode = pack.pack_conv(k[..., sl], None if scale is None else scale[sl],
+                                                None if shift is None else shift[sl], w)
+            consts = {"wt": p.new_const(wt, f"{kernel}:g{g}")}
+            if bvec is not None:
+                consts["bias"] = p.new_const(bvec, f"{kernel}:g{g}:bias")
+            p.add("gemm", [x], out, consts, cite=cite, M=OH * OW, N=wo, K=kk, K_true=kk, mode=mode, H=x.H, W=x.W, Cin=w,
+                  KH=kh, KW=kw, stride=stride, pad_t=pad, pad_l=pad, OH=OH, OW=OW, ldw=wt.shape[1], act=act,
+                  act_after_res=False, out_f32=0, pix_pitch=x.C, a_byte_offset=g * w * 2, out_col=g * wo, ldc=c)
+        return out
+
     def dense(self, x: TRef, kernel: str, bias: Optional[str] = None, *, act="",
               residual: Optional[TRef] = None, out_f32=False, row_select: Optional[Tuple[int, int]] = None,
               in_cols: Optional[Tuple[int, int]] = None,
@@ -822,6 +853,8 @@ class Plan:
                     d.KH, d.KW, d.stride = a["KH"], a["KW"], a["stride"]
                     d.pad_t, d.pad_l, d.OH, d.OW = a["pad_t"], a["pad_l"], a["OH"], a["OW"]
                     d.stride_w = a.get("stride_w", 0)
+                    d.pix_pitch = a.get("pix_pitch", 0)
+                    a_ptr += a.get("a_byte_offset", 0)
                 d.a = a_ptr
                 d.wt = self.cptr(op.consts["wt"])
                 d.bias = self.cptr(op.consts.get("bias"))

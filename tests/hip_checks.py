@@ -705,6 +705,39 @@ CASES["dwconv_k5_s2_same_95_c192"] = lambda: _dw_case(2, 95, 95, 192, 5, 2, "sam
 CASES["dwconv_k3_p1_generic_c6"] = lambda: _dw_case(2, 8, 8, 6, 3, 1, 1, "relu", 95)
 
 
+def _grouped_slice_case(B, H, W, C, groups, stride, act, seed, tile=0):
+    """Conv2D(3x3, groups) as one tfimm_hip_gemm launch per group on the group's channel slice (pix_pitch, pointer offsets)"""
+    import hip_ops as Hh
+    r = _rng(seed)
+    w = C // groups
+    x = _bf(r.standard_normal((B, H, W, C)))
+    kern = (r.standard_normal((3, 3, w, C)) / math.sqrt(9 * w)).astype(np.float32)
+    scale = r.uniform(0.5, 1.5, C).astype(np.float32)
+    shift = r.standard_normal(C).astype(np.float32)
+    kf = _bf(kern * scale.reshape(1, 1, 1, -1))
+    y = O.conv2d(O.zero_pad2d(torch.from_numpy(x), 1), torch.from_numpy(kf), None, stride=stride, groups=groups)
+    y = O.activation(y + torch.from_numpy(shift), act)
+    OH, OW = y.shape[1], y.shape[2]
+    xd = Hh.dev_bf16(x)
+    out = torch.zeros(B * OH * OW, C, dtype=torch.bfloat16, device=Hh.DEV)
+    for g in range(groups):
+        sl = slice(g * w, (g + 1) * w)
+        wt, bias, K, mode = pack.pack_conv(kern[..., sl], scale[sl], shift[sl], w)
+        conv = dict(mode=mode, B=B, H=H, W=W, Cin=w, KH=3, KW=3, stride=stride, pad_t=1, pad_l=1, OH=OH, OW=OW, pix_pitch=C)
+        Hh.gemm(xd, Hh.dev_bits(wt), w, K, bias=Hh.dev_f32(bias), act=act, conv=conv, out=out, ldc=C, tile_hint=tile,
+                a_byte_offset=g * w * 2, out_byte_offset=g * w * 2)
+    Hh.sync()
+    return _err(_cpu(out).reshape(y.shape), y.numpy()), TOL_BF16
+
+
+CASES["grouped_slice_2x64_default"] = lambda: _grouped_slice_case(2, 14, 14, 128, 2, 1, "relu", 320)
+CASES["grouped_slice_4x96_s2_generic_k"] = lambda: _grouped_slice_case(2, 15, 13, 384, 4, 2, "relu", 321)      # Cin % 64 != 0
+CASES["grouped_slice_2x128_dma_family"] = lambda: _grouped_slice_case(3, 9, 9, 256, 2, 1, "", 322, tile=13)
+CASES["grouped_slice_2x64_register_family"] = lambda: _grouped_slice_case(2, 10, 10, 128, 2, 1, "relu", 323, tile=3)
+CASES["grouped_slice_2x64_deep_ring"] = lambda: _grouped_slice_case(2, 32, 32, 128, 2, 1, "relu", 324, tile=28)
+CASES["grouped_slice_3x8_narrow"] = lambda: _grouped_slice_case(2, 7, 7, 24, 3, 1, "relu", 325)
+
+
 def _expand_dw_case(B, H, W, cin, c, k, stride, padding, act, seed, squeeze=True):
     """tfimm_hip_expand_dwconv against 1x1 conv + act (rounded to bf16, as the two-launch path stores it) + depthwise + act"""
     import hip_ops as Hh

@@ -46,7 +46,7 @@ def ptr(t):
 
 def gemm(a, wt, N, K, *, M=None, bias=None, residual=None, out=None, act="", act_after_res=False,
          out_f32=False, lda=None, ldc=None, ldr=None, res_mod=0, remap=None, conv=None, a_scale=None,
-         rows_per_image=0, tile_hint=0, out_rows=None):
+         rows_per_image=0, tile_hint=0, out_rows=None, a_byte_offset=0, out_byte_offset=0):
     """conv: dict(mode, B, H, W, Cin, KH, KW, stride, pad_t, pad_l, OH, OW)."""
     d = ffi.GemmDesc()
     if conv is None:
@@ -59,6 +59,7 @@ def gemm(a, wt, N, K, *, M=None, bias=None, residual=None, out=None, act="", act
         d.KH, d.KW, d.stride = conv["KH"], conv["KW"], conv["stride"]
         d.pad_t, d.pad_l, d.OH, d.OW = conv["pad_t"], conv["pad_l"], conv["OH"], conv["OW"]
         d.stride_w = conv.get("stride_w", 0)
+        d.pix_pitch = conv.get("pix_pitch", 0)
         M = conv["B"] * conv["OH"] * conv["OW"]
     d.M, d.N, d.K = M, N, K
     d.ldw = wt.shape[1]
@@ -68,6 +69,10 @@ def gemm(a, wt, N, K, *, M=None, bias=None, residual=None, out=None, act="", act
         if ldc or remap:
             out.zero_()
     d.a, d.wt, d.bias, d.residual, d.out = ptr(a), ptr(wt), ptr(bias), ptr(residual), ptr(out)
+    if a_byte_offset:
+        d.a = ptr(a) + a_byte_offset
+    if out_byte_offset:
+        d.out = ptr(out) + out_byte_offset
     d.ldc = ldc or N
     d.ldr = ldr or (residual.shape[-1] if residual is not None else 0)
     d.out_f32 = 1 if out_f32 else 0

@@ -132,6 +132,13 @@ if not is_model("vit_test_model"):
                                     nb_blocks=(1, 1, 1, 1), nb_channels=(16, 32, 48, 64), cardinality=4, base_width=16)
 
     @register_model
+    def resnext_wide_test_model():
+        """ResNeXt with wide groups (2 groups of 32 / 64 / 96 / 128 channels): the per-group implicit-GEMM launches on channel
+        slices, as the ResNeXt-101 32x16d / 32d / 48d checkpoints need them."""
+        return ResNet, ResNetConfig(name="resnext_wide_test_model", nb_classes=10, input_size=(64, 64), block="bottleneck",
+                                    nb_blocks=(1, 1, 1, 1), nb_channels=(16, 32, 48, 64), cardinality=2, base_width=128)
+
+    @register_model
     def ecaresnet_test_model():
         """ECA channel attention (layers/attention.py:78-130): Conv1D kernel size 3 at 32 channels, 5 at 128."""
         return ResNet, ResNetConfig(name="ecaresnet_test_model", nb_classes=10, input_size=(64, 64), block="bottleneck",

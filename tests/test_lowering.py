@@ -132,11 +132,21 @@ def test_chain_switch(monkeypatch):
     assert "conv_chain" not in kinds and abs(prog.flops_per_image() / 1e9 - 8.178) < 0.01
 
 
-def test_wide_grouped_convolutions_are_refused_with_a_reason():
-    """ig_resnext101_32x48d: 48..384 channels per group -- neither the super-group kernel nor a sane dense expansion"""
-    m = tfimm.create_model("ig_resnext101_32x32d")
-    with pytest.raises(NotImplementedError, match="MiB dense kernel"):
-        m.program(64, 64)
+def test_wide_groups_run_as_one_gemm_per_group_on_channel_slices():
+    """groups of 64+ channels (ResNeXt-101 32x16d / 32d / 48d): neither the super-group kernel nor a block-diagonal dense
+    expansion -- one implicit-GEMM launch per group that gathers its channel slice in place (pix_pitch) and writes its
+    slice of the output (ldc, out_col)"""
+    kinds, prog = _kinds("resnext_wide_test_model")
+    grouped = [op for op in prog.ops if op.kind == "grouped_conv"]
+    split = [op for op in prog.ops if op.kind == "gemm" and op.attrs.get("pix_pitch")]
+    assert [op.attrs["C"] for op in grouped] == [64]                       # 2 groups of 32: one super-group each
+    assert [(op.attrs["Cin"], op.attrs["pix_pitch"], op.attrs["a_byte_offset"], op.attrs["out_col"], op.attrs["ldc"])
+            for op in split] == [(64, 128, 0, 0, 128), (64, 128, 128, 64, 128), (96, 192, 0, 0, 192), (96, 192, 192, 96, 192),
+                                 (128, 256, 0, 0, 256), (128, 256, 256, 128, 256)]
+    assert all(op.attrs["K"] == 9 * op.attrs["Cin"] and op.attrs["N"] == op.attrs["Cin"] for op in split)
+    assert len({op.output for op in split}) == 3                           # the two groups of a layer share one output tensor
+    for name in ("ig_resnext101_32x16d", "ig_resnext101_32x32d", "ig_resnext101_32x48d"):
+        tfimm.create_model(name).check_supported()
 
 
 def test_every_registered_resnet_is_supported():
