@@ -119,9 +119,24 @@ typedef struct tfimm_gemm_desc {
                              pix_pitch = C the convolution reads the channel slice [c0, c0 + w) -- one group of a
                              grouped convolution (resnet.py:229-236); ldc / the `out` pointer place its w output
                              channels the same way. */
+  const float* ln_stats;  /* dense mode, no residual: fp32 [M][2] = (mean, rstd) of every row of `a` (tfimm_hip_row_stats).
+                             With ln_c1 it folds a LayerNormalization over the K axis INTO this layer
+                             (layers/factory.py:42-50 in front of a Dense, vit.py:226-233, swin.py:243-327):
+                             out = act(rstd_m * (a . wt^T - mean_m * c1[n]) + bias[n]), where the caller has already
+                             multiplied gamma into wt (W' = gamma * W, then rounded to bf16), c1[n] = sum_k W'[k][n] of the
+                             ROUNDED weights and bias = beta . W + b.  The normalised tensor is never written. */
+  const void* ln_c1;      /* bf16 [N][2][8]: c1[n] as the three-term bf16 split (ca, cb, cc), laid out as the MFMA fragment
+                             pair {ca,cb,cc,ca,cb,cc,ca,cb} {cc,0,0,0,0,0,0,0} (tfimm/engine/pack.py: pack_ln_c1) */
 } tfimm_gemm_desc;
 
 TFIMM_API int tfimm_hip_gemm(const tfimm_gemm_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * tfimm_hip_row_stats: stats[r] = (mean, 1 / sqrt(var + eps)) over the d channels of row r (fp32 two-pass, population
+ * variance -- tf.keras.layers.LayerNormalization's statistics), for a LayerNorm that is folded into the following
+ * tfimm_hip_gemm (ln_stats / ln_c1).  x: bf16 rows of x_stride elements.
+ * ------------------------------------------------------------------------------------- */
+TFIMM_API int tfimm_hip_row_stats(const void* x, float* stats, int64_t rows, int d, int64_t x_stride, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * tfimm_hip_cast_input: float32 / bf16 NHWC image batch -> bf16 NHWC with channels padded

@@ -163,6 +163,9 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
   if (d.mode < 0 || d.mode > 2) TFIMM_FAIL(TFIMM_EINVAL, "gemm: mode=%d", d.mode);
   if (d.remap_in < 0 || d.res_mod < 0) TFIMM_FAIL(TFIMM_EINVAL, "gemm: negative remap/res_mod");
   if (d.bias && ((uintptr_t)d.bias & 15)) TFIMM_FAIL(TFIMM_EINVAL, "gemm: bias must be 16-byte aligned");
+  if ((d.ln_stats != nullptr) != (d.ln_c1 != nullptr)) TFIMM_FAIL(TFIMM_EINVAL, "gemm: ln_stats and ln_c1 go together");
+  if (d.ln_stats && (d.mode != TFIMM_A_DENSE || d.residual || d.a_scale || d.out_f32 || (((uintptr_t)d.ln_stats | (uintptr_t)d.ln_c1) & 15)))
+    TFIMM_FAIL(TFIMM_EINVAL, "gemm: LayerNorm folding needs a dense bf16 layer without residual / gate and 16-byte aligned tables");
 
   // The LDS-DMA kernels address every tensor through a buffer descriptor with a 32-bit byte offset.  A plain
   // dense GEMM whose activation, output or residual exceeds 2 GiB (EfficientNet-B4's first expand layer at batch 256:
@@ -179,6 +182,7 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
         c.a = (const char*)d.a + m0 * d.lda * 2;
         c.out = (char*)d.out + m0 * d.ldc * (d.out_f32 ? 4 : 2);
         if (d.residual) c.residual = (const char*)d.residual + m0 * d.ldr * 2;
+        if (d.ln_stats) c.ln_stats = d.ln_stats + m0 * 2;
         const int rc = tfimm_hip_gemm(&c, stream);
         if (rc != 0) return rc;
       }
@@ -241,7 +245,7 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
     const int64_t a_bytes = (d.mode == TFIMM_A_DENSE) ? ((int64_t)(d.M - 1) * d.lda + d.K) * 2
                                                        : (((int64_t)d.B * d.H * d.W - 1) * g.cpitch + d.Cin) * 2;
     const int64_t w_bytes = (int64_t)d.N * d.ldw * 2;
-    const bool hinted_other = d.tile_hint > 0 && d.tile_hint <= 20 && g.stride_w == g.stride;
+    const bool hinted_other = d.tile_hint > 0 && d.tile_hint <= 20 && g.stride_w == g.stride && !d.ln_stats;
     // extents of the output / residual buffers as the epilogue addresses them (row remap included)
     const int64_t out_rows = d.remap_in > 0 ? ((int64_t)(d.M - 1) / d.remap_in) * d.remap_out + d.remap_in + d.remap_off : d.M;
     const int64_t out_bytes = ((out_rows - 1) * d.ldc + d.N) * (d.out_f32 ? 4 : 2);
@@ -279,6 +283,15 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
         ti = 0;
         t = stream_tile_table(ti);
       }
+      const bool ln_in = d.ln_stats != nullptr;
+      if (ln_in) {
+        if (ei != 2 || fi != 0 || scale)
+          TFIMM_FAIL(TFIMM_EUNSUP, "gemm: LayerNorm folding needs dense bf16 rows, N %% 8 == 0, 16-byte aligned output, no residual");
+        if (!t->fn_ln || (size_t)t->lds_bytes + t->ln_lds > 160 * 1024) {
+          ti = 0;
+          t = stream_tile_table(ti);
+        }
+      }
       GemmStreamArgs ga;
       ga.g = g;
       ga.g.tiles_m = (int)cdiv64(d.M, t->bm);
@@ -307,6 +320,23 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       const int64_t need = (ntiles + 7) / 8 * 8;
       if (grid > need) grid = need;
       ga.s_bytes = 0; ga.s_slots = ga.s_stride = ga.s_pieces = 0;
+      ga.ln_stats = d.ln_stats; ga.ln_c1 = d.ln_c1;
+      ga.ln_stats_bytes = ln_in ? (unsigned)((int64_t)d.M * 8) : 0u;
+      ga.ln_c1_bytes = ln_in ? (unsigned)((int64_t)d.N * 32) : 0u;
+      if (ln_in) {
+        const size_t lds = (size_t)t->lds_bytes + t->ln_lds;
+        static int ln_occ[TFIMM_GEMM_STREAM_NUM_TILES] = {};
+        if (!ln_occ[ti]) {
+          TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)t->fn_ln, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          int nb = 0;
+          TFIMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)t->fn_ln, t->threads, lds));
+          ln_occ[ti] = nb < 1 ? 1 : (nb > 4 ? 4 : nb);
+        }
+        grid = ((int64_t)num_cu() * ln_occ[ti] + 7) / 8 * 8;
+        if (grid > need) grid = need;
+        TFIMM_LAUNCH(t->fn_ln, dim3((unsigned)grid), dim3(t->threads), lds, (hipStream_t)stream, ga);
+        return 0;
+      }
       if (!scale) {
         TFIMM_LAUNCH(t->fn[fi][ei], dim3((unsigned)grid), dim3(t->threads), (size_t)t->lds_bytes, (hipStream_t)stream, ga);
         return 0;
@@ -337,6 +367,7 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
     }
   }
 
+  if (d.ln_stats) TFIMM_FAIL(TFIMM_EUNSUP, "gemm: LayerNorm folding needs the persistent LDS-DMA family (K-padded weights, 16-byte aligned rows)");
   if (d.mode != TFIMM_A_DENSE && g.stride_w != g.stride)
     TFIMM_FAIL(TFIMM_EUNSUP, "gemm: stride_w != stride needs the persistent LDS-DMA family (Cin %% 8 == 0, 16-byte aligned input)");
 

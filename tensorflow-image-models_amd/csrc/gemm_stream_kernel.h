@@ -48,6 +48,10 @@ struct GemmStreamArgs {
   int s_slots;        // image slots per tile: ceil(BM / rows_per_image) + 1
   int s_stride;       // floats per slot (K rounded up to whole 1-KiB DMA pieces)
   int s_pieces;       // DMA pieces per wave and tile (slots * stride / 256 / waves, rounded up)
+  // LNIN flavour (LayerNorm folded into this GEMM): per-row (mean, rstd) and the split column sums of the gamma-scaled weights
+  const float* ln_stats;      // fp32 [M][2]
+  const void* ln_c1;          // bf16 [N][2][8] correction fragments (pack.pack_ln_c1)
+  unsigned ln_stats_bytes, ln_c1_bytes;
   long long* dbg_ptr; // TFIMM_GEMM_DBG_PTR: s_memtime stamps of workgroup 0 (dbg & 64)
   int dbg;           // TFIMM_GEMM_DBG: bit 64 = record the stamps (tools/gemm_stamps.py)
 };
@@ -66,7 +70,12 @@ struct StreamGeom {
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit in LDS");
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int KMODE, bool VEC, bool SCALE = false, bool NORES = false>
+// LNIN: the A operand is the RAW input of a LayerNormalization that the host folded into this layer -- the weights carry gamma,
+// the bias carries beta . W, and  LN(x) . W = rstd_m * (x . W' - mean_m * c1[n]) + b'[n]  with c1[n] = sum_k W'[k][n].
+// -mean_m * c1[n] is a rank-1 update: ONE extra MFMA k-step per accumulator block whose operands are the bf16 three-way splits
+// of -mean_m (built in registers) and of c1[n] (host-packed), nine exact products that carry ~24 bits; rstd_m rides on the
+// bias FMA.  Statistics and correction fragments of a tile arrive by LDS-DMA at tile start (no registers across the K loop).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KMODE, bool VEC, bool SCALE = false, bool NORES = false, bool LNIN = false>
 __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(const GemmStreamArgs pa) {
   using G = StreamGeom<BM, BN, WAVES_M, WAVES_N>;
   const GemmArgs& p = pa.g;
@@ -79,6 +88,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   static_assert(KMODE == K_DENSE || KMODE == K_CONV, "LDS-DMA flavours: dense rows or Cin % 8 == 0 gather");
   static_assert(WTN == 32 || WTN == 64, "epilogue swizzle is written for 32/64-wide wave tiles");
   static_assert(!SCALE || KMODE == K_DENSE, "the SE-gate prologue exists for dense rows");
+  static_assert(!LNIN || (VEC && NORES && !SCALE && KMODE == K_DENSE), "LayerNorm folding: dense rows, residual-free vector epilogue");
   constexpr int A_BYTES = G::A_BYTES, STAGE = G::STAGE;
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
@@ -107,7 +117,11 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(p.wt, pa.w_bytes);
   const __amdgpu_buffer_rsrc_t rsrc_o = make_rsrc(p.out, pa.out_bytes);
   const __amdgpu_buffer_rsrc_t rsrc_r = make_rsrc(p.residual, pa.res_bytes);
-  const __amdgpu_buffer_rsrc_t rsrc_s = make_rsrc(p.a_scale, SCALE ? pa.s_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rsrc_s = LNIN ? make_rsrc(pa.ln_stats, pa.ln_stats_bytes) : make_rsrc(p.a_scale, SCALE ? pa.s_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rsrc_c = make_rsrc(pa.ln_c1, LNIN ? pa.ln_c1_bytes : 0u);
+  // LNIN: this wave's private LDS block behind the operand ring: 1 KiB of (mean, rstd) pairs for 128 rows, then TN x 1 KiB
+  // of correction fragments (one 16-byte fragment per lane and 32-column block)
+  char* const lnw = smem + G::LDS_BYTES + wave * (1 + TN) * 1024;
   // gate region: two buffers (tile being multiplied / tile being issued) of s_pieces * NW pieces of 256 floats
   float* const sS = reinterpret_cast<float*>(smem + G::LDS_BYTES);
   const int s_buf_floats = SCALE ? pa.s_pieces * NW * 256 : 0;
@@ -308,6 +322,16 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
         bfast = f32x4{b4.x, b4.y, b4.z, b4.w};
       }
     }
+    if (LNIN) {
+      // rows m0 + wm*WTM + 2*lane, +1: 16 bytes per lane; rows >= M and columns >= N are beyond the descriptors (zeros)
+      const unsigned so = (unsigned)(m0 + wm * WTM) * 8u + (unsigned)lane * 16u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_s, (lds_ptr_t)lnw, 16, (int)so, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const unsigned co = (unsigned)(((n0 + wn * WTN + j * 32 + (lane & 31)) * 2 + (lane >> 5)) * 16);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_c, (lds_ptr_t)(lnw + (1 + j) * 1024), 16, (int)co, 0, 0, 0);
+      }
+    }
     if (VEC) {
       const bool col_ok = e_n < p.N;   // N % 8 == 0: all 8 channels or none
       if (!fast_epi && p.bias && col_ok) {
@@ -480,8 +504,48 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
           const int rsw = CPR == 8 ? ((pr >> 1) & 7) : ((pr >> 2) & 3);
           rb_addr[it] = (unsigned)(size_t)(lds_ptr_t)(sE16 + pr * (WTN * 2) + ((e_c8 ^ rsw) * 16));
         }
+        u32x4 cfr[TN];
+        if (LNIN) {
+          // with a single k-tile no later step has waited for this tile's table DMA yet
+          if (nk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          const unsigned ca = (unsigned)(size_t)(lds_ptr_t)(lnw + 1024 + lane * 16);
+          if (TN == 2) {
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(cfr[0]), "=&v"(cfr[TN - 1]) : "v"(ca) : "memory");
+          } else {
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(cfr[0]) : "v"(ca) : "memory");
+          }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+          tfimm_f32x2 rs2 = {1.f, 1.f};
+          if (LNIN) {
+            // (mean, rstd) of this lane's row of pass i; -mean as three bf16 terms (exact residuals) in the k-slots that meet
+            // the (ca, cb, cc) pattern of the column fragments: k0..8 = m1 ca, m1 cb, m1 cc, m2 ca, m2 cb, m2 cc, m3 ca, m3 cb, m3 cc
+            tfimm_f32x2 st;
+            const unsigned sa = (unsigned)(size_t)(lds_ptr_t)(lnw + (i * 32 + frow) * 8);
+            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(st) : "v"(sa) : "memory");
+            const float nm = -st[0];
+            const uint32_t b1 = __float_as_uint(nm) & 0xffff0000u;
+            const float r1 = nm - __uint_as_float(b1);
+            const uint32_t b2 = __float_as_uint(r1) & 0xffff0000u;
+            const float r2 = r1 - __uint_as_float(b2);
+            const uint32_t b3 = __float_as_uint(r2) & 0xffff0000u;
+            u32x4 fx;
+            fx[0] = fhi ? (b3 >> 16) : (b1 | (b1 >> 16));
+            fx[1] = fhi ? 0u : (b2 | (b1 >> 16));
+            fx[2] = fhi ? 0u : (b2 | (b2 >> 16));
+            fx[3] = fhi ? 0u : (b3 | (b3 >> 16));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cfr[j]), __builtin_bit_cast(bf16x8, fx),
+                                                                  acc[i][j], 0, 0, 0);
+            rs2 = tfimm_f32x2{st[1], st[1]};
+            // a real register pair: folded into the FMAs as an operand select (v_pk_fma_f32 ... op_sel:[0,1,0] on the
+            // (mean, rstd) pair the ds_read_b64 returned) the LOW products came out as 0 * rstd for runs of 8 lanes, racily, on
+            // the 32-column wave tiles (tools/_lnprobe2.py: 8..20 bad launches of 20; none with the pair materialised)
+            asm volatile("" : "+v"(rs2));
+          }
           if (TN == 2) {
             asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[i][0]), "+v"(acc[i][TN - 1]));
           } else {
@@ -496,8 +560,15 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
               for (int h2 = 0; h2 < 2; ++h2) {
                 const int q = q2 * 2 + h2;
                 const f32x4 b4 = __builtin_bit_cast(f32x4, bq[j * 4 + q]);
+                if (LNIN) {
+                  v[h2 * 2 + 0] = __builtin_elementwise_fma(tfimm_f32x2{acc[i][j][q * 4 + 0], acc[i][j][q * 4 + 1]}, rs2,
+                                                            tfimm_f32x2{b4[0], b4[1]});
+                  v[h2 * 2 + 1] = __builtin_elementwise_fma(tfimm_f32x2{acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]}, rs2,
+                                                            tfimm_f32x2{b4[2], b4[3]});
+                } else {
                 v[h2 * 2 + 0] = tfimm_f32x2{acc[i][j][q * 4 + 0] + b4[0], acc[i][j][q * 4 + 1] + b4[1]};
                 v[h2 * 2 + 1] = tfimm_f32x2{acc[i][j][q * 4 + 2] + b4[2], acc[i][j][q * 4 + 3] + b4[3]};
+                }
               }
               act8p(v, actp);
               const uint4 pk = pack8p(v);
@@ -645,6 +716,8 @@ struct StreamTileCfg {
   int bm, bn, threads, lds_bytes;
   gemm_stream_fn fn[2][3];     // [K_DENSE, K_CONV][catch-all, VEC, VEC without residual]
   gemm_stream_fn fn_scale[3];  // K_DENSE + SE gate on A, same three epilogues (null: not built for this tile)
+  gemm_stream_fn fn_ln;        // K_DENSE, VEC without residual, LayerNorm folded in (LNIN); needs ln_lds extra bytes of LDS
+  int ln_lds;
 };
 
 }  // namespace tfimm_gemm

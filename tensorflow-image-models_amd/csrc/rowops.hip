@@ -4,6 +4,7 @@
 // whenever the channel count allows it.  Reference call sites: include/tfimm_hip.h.
 #include "common.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1189,6 +1190,69 @@ extern "C" int tfimm_hip_preprocess_input_pad(const void* in, void* out, int B, 
   const unsigned grid = grid_for((int64_t)B * HP * WP, 256);
   TFIMM_LAUNCH(preprocess_pad4_kernel, dim3(grid), dim3(256), 0, st, (const uint8_t*)in, (uint2*)out, B, H, W, c_in, pad_t,
                pad_l, HP, WP, np);
+  return 0;
+}
+
+// Row statistics for a LayerNorm that is folded into the following GEMM (tfimm_gemm_desc.ln_stats): the same fp32 two-pass
+// mean / population variance as the LayerNorm kernels above, the row held in registers, but nothing is written except
+// (mean, rstd) -- half the traffic of the normalising pass.  LPR lanes per row, up to 4 chunks of 16 bytes per lane.
+template <int LPR>
+__global__ void __launch_bounds__(256) row_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ stats, int64_t rows,
+                                                        int d, int64_t xs, float eps) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / LPR, c = lane % LPR;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int nchunks = d >> 3;
+  const float inv_d = 1.f / (float)d;
+  auto group_sum = [&](float v) -> float {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  for (int64_t r0 = wave0 * RPW; r0 < rows; r0 += nwaves * RPW) {
+    const int64_t r = r0 + sub;
+    const bool rok = r < rows;
+    float v[4][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint4 u = make_uint4(0u, 0u, 0u, 0u);
+      if (rok && c + i * LPR < nchunks) u = reinterpret_cast<const uint4*>(x + r * xs)[c + i * LPR];
+      unpack8(u, v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += v[i][e];
+    }
+    const float mean = group_sum(sum) * inv_d;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (c + i * LPR < nchunks) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float t = v[i][e] - mean;
+          sq += t * t;
+        }
+      }
+    const float rstd = rsqrtf(group_sum(sq) * inv_d + eps);
+    if (rok && c == 0) *reinterpret_cast<float2*>(stats + r * 2) = make_float2(mean, rstd);
+  }
+}
+
+extern "C" int tfimm_hip_row_stats(const void* x, float* stats, int64_t rows, int d, int64_t x_stride, float eps, void* stream) {
+  if (!x || !stats) TFIMM_FAIL(TFIMM_EINVAL, "row_stats: null pointer");
+  if (rows <= 0 || d <= 0 || x_stride < d) TFIMM_FAIL(TFIMM_EINVAL, "row_stats: bad shape");
+  if ((d & 7) || (x_stride & 7) || ((uintptr_t)x & 15) || ((uintptr_t)stats & 7) || d > 2048)
+    TFIMM_FAIL(TFIMM_EUNSUP, "row_stats: rows of d %% 8 == 0 <= 2048 channels, 16-byte aligned");
+  const int nchunks = d >> 3;
+  hipStream_t st = (hipStream_t)stream;
+  const bf16_t* xb = (const bf16_t*)x;
+  auto grid_for = [&](int rpw) { return (unsigned)std::min<int64_t>((rows + 4 * rpw - 1) / (4 * rpw), 65536); };
+  if (nchunks <= 32) TFIMM_LAUNCH(row_stats_kernel<8>, dim3(grid_for(8)), dim3(256), 0, st, xb, stats, rows, d, x_stride, eps);
+  else if (nchunks <= 64) TFIMM_LAUNCH(row_stats_kernel<16>, dim3(grid_for(4)), dim3(256), 0, st, xb, stats, rows, d, x_stride, eps);
+  else if (nchunks <= 128) TFIMM_LAUNCH(row_stats_kernel<32>, dim3(grid_for(2)), dim3(256), 0, st, xb, stats, rows, d, x_stride, eps);
+  else TFIMM_LAUNCH(row_stats_kernel<64>, dim3(grid_for(1)), dim3(256), 0, st, xb, stats, rows, d, x_stride, eps);
   return 0;
 }
 

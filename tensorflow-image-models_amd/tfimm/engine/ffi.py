@@ -37,6 +37,7 @@ class GemmDesc(C.Structure):
         ("pad_t", C.c_int32), ("pad_l", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32),
         ("rows_per_image", C.c_int32), ("tile_hint", C.c_int32), ("stride_w", C.c_int32),
         ("pix_pitch", C.c_int32),
+        ("ln_stats", C.c_void_p), ("ln_c1", C.c_void_p),
     ]
 
 
@@ -105,6 +106,7 @@ SYMBOLS = {
     "tfimm_hip_preprocess_input": (_i, [_vp, _vp, _i64, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
     "tfimm_hip_preprocess_input_pad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float),
                                             C.POINTER(C.c_float), _vp]),
+    "tfimm_hip_row_stats": (_i, [_vp, _vp, _i64, _i, _i64, _f, _vp]),
     "tfimm_hip_layernorm": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i64, _i64, _f, _vp]),
     "tfimm_hip_attention": (_i, [C.POINTER(AttnDesc), _vp]),
     "tfimm_hip_talking_heads_attention": (_i, [C.POINTER(ThaDesc), _vp]),

@@ -435,8 +435,12 @@ class Builder:
               in_cols: Optional[Tuple[int, int]] = None,
               out: Optional[TRef] = None, out_col: int = 0, out_scale: Optional[str] = None,
               residual_row: Optional[int] = None, out_row: Optional[int] = None,
-              cite="", name="") -> TRef:
+              ln: Optional[Tuple[str, float, TRef]] = None, cite="", name="") -> TRef:
         """tf.keras.layers.Dense (+ activation, + residual add).
+
+        ``ln=(prefix, eps, stats)``: ``x`` is the RAW input of LayerNormalization ``prefix`` whose output this layer reads;
+        the normalisation is folded into the layer (gamma into the weights, beta . W into the bias, per-row mean / rstd
+        from ``stats`` = ``row_stats(x, eps)`` applied in the GEMM epilogue) and the normalised tensor never exists.
 
         ``row_select=(first_row, count)`` applies the layer to ``count`` rows per image
         starting at ``first_row`` (e.g. the class token x[:, 0], vit.py:462) without a copy.
@@ -464,6 +468,13 @@ class Builder:
             assert kin == x.C, f"{kernel}: in={kin} but tensor has C={x.C}"
         else:
             assert in_cols[1] == kin and in_cols[0] + kin <= x.C
+        if ln is not None:
+            assert residual is None and row_select is None and in_cols is None and not out_f32 and out is None
+            assert kin % 8 == 0 and kout % 8 == 0
+            gam, bet = self.wget(ln[0] + "/gamma").astype(np.float64), self.wget(ln[0] + "/beta").astype(np.float64)
+            shift = bet @ k.astype(np.float64)                     # beta . W (+ b): what LN's beta contributes to every row
+            bvec_in = (shift if bvec_in is None else shift + bvec_in).astype(np.float32)
+            k = (k.astype(np.float64) * gam.reshape(kin, 1)).astype(np.float32)
         wt, bvec = pack.pack_dense(k, bvec_in)
         rows = x.rows
         attrs = dict(M=rows, N=kout, K=kin, K_true=kin, mode=0, lda=x.C, act=act, act_after_res=False,
@@ -486,10 +497,15 @@ class Builder:
             assert rows == 1 and out.C == kout and out_row < out.rows
             attrs["ldc"] = out.rows * out.C
             attrs["out_byte_offset"] = out_row * out.C * out.itemsize
-        consts = {"wt": p.new_const(wt, kernel)}
+        consts = {"wt": p.new_const(wt, kernel + (":ln" if ln is not None else ""))}
         if bvec is not None:
-            consts["bias"] = p.new_const(bvec, kernel + ":bias")
+            consts["bias"] = p.new_const(bvec, kernel + (":ln:bias" if ln is not None else ":bias"))
         ins = [x]
+        if ln is not None:
+            consts["ln_c1"] = p.new_const(pack.pack_ln_c1(wt, kout, kin), kernel + ":ln_c1")
+            assert ln[2].rows == x.rows and ln[2].C == 2
+            ins.append(ln[2])
+            attrs["ln"] = True
         if residual is not None:
             assert residual.C == kout
             ins.append(residual)
@@ -508,6 +524,16 @@ class Builder:
         return self.p.new_tensor(rows, C, dtype=dtype, name=name)
 
     # -- normalisation -----------------------------------------------------------------------
+    def can_fold_ln(self, x: TRef) -> bool:
+        """LayerNormalization over x's channels can be folded into the Dense layers that read it (dense(..., ln=...))."""
+        return x.C % 8 == 0 and x.C <= 2048 and os.environ.get("TFIMM_NO_LN_FOLD", "0") != "1"
+
+    def row_stats(self, x: TRef, eps: float, cite="") -> TRef:
+        """(mean, rstd) of every row of x -- the statistics of a LayerNormalization that is folded into its consumers."""
+        st = self.p.new_tensor(x.rows, 2, dtype="f32", name="ln_stats")
+        self.p.add("row_stats", [x], st, cite=cite, rows=x.rows, d=x.C, eps=float(eps))
+        return st
+
     def layernorm(self, x: TRef, prefix: str, eps: float, *, row_select=None, out: Optional[TRef] = None,
                   out_col: int = 0, cite="", name="") -> TRef:
         """LayerNormalization over the channel axis.  ``row_select=(row, 1)`` normalises one
@@ -866,6 +892,10 @@ class Plan:
                 d.act = ffi.ACT[a["act"]]
                 d.act_after_res = 1 if a["act_after_res"] else 0
                 idx = 1
+                if a.get("ln"):
+                    d.ln_stats = self.tptr(op.inputs[idx])
+                    d.ln_c1 = self.cptr(op.consts["ln_c1"])
+                    idx += 1
                 if a.get("has_residual"):
                     d.residual = self.tptr(op.inputs[idx]) + a.get("res_byte_offset", 0)
                     idx += 1
@@ -915,6 +945,9 @@ class Plan:
                 self.calls.append((lib.tfimm_hip_grouped_conv3x3,
                                    (self.tptr(op.inputs[0]), self.cptr(op.consts["w"]), self.cptr(op.consts["bias"]),
                                     self.tptr(op.output), B, a["H"], a["W"], a["C"], a["stride"], ffi.ACT[a["act"]])))
+            elif k == "row_stats":
+                self.calls.append((lib.tfimm_hip_row_stats,
+                                   (self.tptr(op.inputs[0]), self.tptr(op.output), B * a["rows"], a["d"], a["d"], a["eps"])))
             elif k == "layernorm":
                 xp = self.tptr(op.inputs[0]) + a["x_byte_offset"]
                 self.calls.append((lib.tfimm_hip_layernorm,

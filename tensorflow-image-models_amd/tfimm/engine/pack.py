@@ -170,3 +170,28 @@ def pack_expand_frag(w1: np.ndarray, cpad: int) -> np.ndarray:
     k = (16 * np.arange(2)[:, None, None] + 8 * (lane >> 5)[None, :, None] + np.arange(8)[None, None, :])    # [2][64][8]
     ch = 32 * np.arange(cpad // 32)[:, None, None, None] + (lane & 31)[None, None, :, None]                # [cc][1][64][1]
     return to_bf16_bits(full[k[None], ch])
+
+
+def split3_bf16(v: np.ndarray) -> np.ndarray:
+    """fp32 values as three bf16 terms (truncation splits with exact residuals): v ~= t0 + t1 + t2 to ~24 bits.
+    Returns uint16 [..., 3]."""
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    out = np.zeros(v.shape + (3,), np.uint16)
+    r = v.copy()
+    for i in range(3):
+        bits = r.view(np.uint32) & np.uint32(0xFFFF0000)
+        out[..., i] = (bits >> 16).astype(np.uint16)
+        r = r - bits.view(np.float32)
+    return out
+
+
+def pack_ln_c1(wt_bits: np.ndarray, n: int, k: int) -> np.ndarray:
+    """Correction fragments of a GEMM with a folded LayerNorm (tfimm_gemm_desc.ln_c1): c1[n] = sum_k Wt[n][k] over the
+    bf16-ROUNDED packed weights ``wt_bits`` (uint16 [N][ldw]), split into three bf16 terms (ca, cb, cc) and laid out per column
+    as the MFMA fragment pair {ca, cb, cc, ca, cb, cc, ca, cb} {cc, 0, 0, 0, 0, 0, 0, 0}: uint16 [N][2][8]."""
+    c1 = bf16_bits_to_f32(wt_bits[:n, :k]).astype(np.float64).sum(axis=1).astype(np.float32)
+    t = split3_bf16(c1)                                     # [N][3]
+    out = np.zeros((n, 2, 8), np.uint16)
+    out[:, 0, :] = t[:, [0, 1, 2, 0, 1, 2, 0, 1]]
+    out[:, 1, 0] = t[:, 2]
+    return out

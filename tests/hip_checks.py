@@ -738,6 +738,61 @@ CASES["grouped_slice_2x64_deep_ring"] = lambda: _grouped_slice_case(2, 32, 32, 1
 CASES["grouped_slice_3x8_narrow"] = lambda: _grouped_slice_case(2, 7, 7, 24, 3, 1, "relu", 325)
 
 
+def _row_stats_case(rows, d, seed, offset=0.0):
+    import hip_ops as Hh
+    r = _rng(seed)
+    x = _bf(r.standard_normal((rows, d)) * r.uniform(0.2, 3.0, (rows, 1)) + offset)
+    got = _cpu(Hh.row_stats(Hh.dev_bf16(x), 1e-6))
+    x64 = x.astype(np.float64)
+    ref = np.stack([x64.mean(1), 1.0 / np.sqrt(x64.var(1) + 1e-6)], 1)
+    Hh.sync()
+    return float(np.abs(got - ref).max() / np.abs(ref).max()), 1e-5
+
+
+for _d in (96, 128, 192, 256, 384, 512, 768, 1024, 1536):
+    CASES[f"row_stats_d{_d}"] = (lambda d: lambda: _row_stats_case(203, d, 330 + d, offset=2.0))(_d)
+
+
+def _ln_gemm_case(M, K, N, act, seed, tile=0, offset=0.0, bias=True):
+    """Dense layer with the LayerNormalization in front of it folded in (ln_stats / ln_c1) against LN -> matmul in fp64.
+    ``offset`` shifts the rows' means far from zero: the rank-1 correction then has to cancel a term much larger than the
+    result (the three-way bf16 splits carry it)."""
+    import hip_ops as Hh
+    r = _rng(seed)
+    x = _bf(r.standard_normal((M, K)) * r.uniform(0.5, 2.0, (M, 1)) + offset * r.uniform(0.5, 1.5, (M, 1)))
+    gam = r.uniform(0.5, 1.5, K).astype(np.float32)
+    bet = (0.3 * r.standard_normal(K)).astype(np.float32)
+    w = (r.standard_normal((K, N)) / math.sqrt(K)).astype(np.float32)
+    b = r.standard_normal(N).astype(np.float32) if bias else np.zeros(N, np.float32)
+    eps = 1e-6
+    x64 = x.astype(np.float64)
+    ln = (x64 - x64.mean(1, keepdims=True)) / np.sqrt(x64.var(1, keepdims=True) + eps) * gam + bet
+    y = O.activation(torch.from_numpy((ln @ w.astype(np.float64) + b).astype(np.float32)), act).numpy()
+    wf = (w.astype(np.float64) * gam.reshape(K, 1)).astype(np.float32)
+    bf = (bet.astype(np.float64) @ w.astype(np.float64) + b).astype(np.float32)
+    wt, bvec = pack.pack_dense(wf, bf)
+    c1 = pack.pack_ln_c1(wt, N, K)
+    xd = Hh.dev_bf16(x)
+    st = Hh.row_stats(xd, eps)
+    got = Hh.gemm(xd, Hh.dev_bits(wt), N, K, bias=Hh.dev_f32(bvec), act=act, tile_hint=tile, ln_stats=st, ln_c1=Hh.dev_bits(c1))
+    Hh.sync()
+    return _err(_cpu(got), y), TOL_BF16
+
+
+CASES["ln_gemm_768_2304_qkv"] = lambda: _ln_gemm_case(600, 768, 2304, "", 340)
+CASES["ln_gemm_768_3072_gelu"] = lambda: _ln_gemm_case(520, 768, 3072, "gelu", 341)
+CASES["ln_gemm_mean_offset_20"] = lambda: _ln_gemm_case(300, 512, 512, "", 342, offset=20.0)
+CASES["ln_gemm_128_384_tile128"] = lambda: _ln_gemm_case(1000, 128, 384, "", 343, tile=23)
+CASES["ln_gemm_ragged_rows_cols"] = lambda: _ln_gemm_case(333, 192, 200, "gelu", 344, offset=3.0)
+CASES["ln_gemm_256x128_tile"] = lambda: _ln_gemm_case(777, 256, 768, "", 345, tile=22)
+CASES["ln_gemm_256x64_tile"] = lambda: _ln_gemm_case(515, 384, 192, "", 346, tile=24, bias=False)
+CASES["ln_gemm_128x256_tile"] = lambda: _ln_gemm_case(400, 1024, 1024, "gelu", 347, tile=26)
+for _t in (21, 22, 23, 24, 25, 26, 27, 29):
+    CASES[f"ln_gemm_ragged_tile{_t}"] = (lambda t: lambda: _ln_gemm_case(333, 192, 200, "gelu", 350 + t, tile=t, offset=3.0))(_t)
+CASES["ln_gemm_one_k_tile"] = lambda: _ln_gemm_case(5000, 32, 96, "", 349, offset=1.0)        # nk = 1: the table DMA has to be waited for explicitly
+CASES["ln_gemm_multi_round"] = lambda: _ln_gemm_case(70000, 128, 256, "", 348, offset=1.0)
+
+
 def _expand_dw_case(B, H, W, cin, c, k, stride, padding, act, seed, squeeze=True):
     """tfimm_hip_expand_dwconv against 1x1 conv + act (rounded to bf16, as the two-launch path stores it) + depthwise + act"""
     import hip_ops as Hh

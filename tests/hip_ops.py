@@ -46,7 +46,7 @@ def ptr(t):
 
 def gemm(a, wt, N, K, *, M=None, bias=None, residual=None, out=None, act="", act_after_res=False,
          out_f32=False, lda=None, ldc=None, ldr=None, res_mod=0, remap=None, conv=None, a_scale=None,
-         rows_per_image=0, tile_hint=0, out_rows=None, a_byte_offset=0, out_byte_offset=0):
+         rows_per_image=0, tile_hint=0, out_rows=None, a_byte_offset=0, out_byte_offset=0, ln_stats=None, ln_c1=None):
     """conv: dict(mode, B, H, W, Cin, KH, KW, stride, pad_t, pad_l, OH, OW)."""
     d = ffi.GemmDesc()
     if conv is None:
@@ -85,8 +85,18 @@ def gemm(a, wt, N, K, *, M=None, bias=None, residual=None, out=None, act="", act
         d.a_scale = ptr(a_scale)
         d.rows_per_image = rows_per_image
     d.tile_hint = tile_hint
+    if ln_stats is not None:
+        d.ln_stats, d.ln_c1 = ptr(ln_stats), ptr(ln_c1)
     ffi.check(lib.tfimm_hip_gemm(C.byref(d), stream()), "gemm")
     return out
+
+
+def row_stats(x, eps, rows=None, d=None, xs=None):
+    rows = rows if rows is not None else x.shape[0]
+    d = d if d is not None else x.shape[-1]
+    st = torch.empty(rows, 2, dtype=torch.float32, device=DEV)
+    ffi.check(lib.tfimm_hip_row_stats(ptr(x), ptr(st), rows, d, xs or d, float(eps), stream()), "row_stats")
+    return st
 
 
 def layernorm(x, gamma, beta, eps, rows=None, d=None, xs=None, ys=None, out=None):

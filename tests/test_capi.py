@@ -64,7 +64,8 @@ def test_gemm_desc_layout_matches_header():
         parts = decl.replace("*", " ").split(None, 1)[1] if not decl.startswith("const") else decl.replace("*", " ").split(None, 2)[2]
         names += [n.strip() for n in parts.split(",")]
     assert names == [f[0] for f in ffi.GemmDesc._fields_], names
-    assert ctypes.sizeof(ffi.GemmDesc) == (6 * 8 + 29 * 4 + 7) // 8 * 8
+    # 6 pointers, 30 int32 (168 bytes: already a multiple of 8), 2 pointers
+    assert ctypes.sizeof(ffi.GemmDesc) == 6 * 8 + 30 * 4 + 2 * 8
     # 3 pointers, 4 int32, float, 4 int32 (= 60, padded to 64 for the pointer that follows), 1 pointer
     assert ctypes.sizeof(ffi.AttnDesc) == 64 + 8
 
