@@ -172,13 +172,13 @@ class CaiT(Model):
 
         for j in range(c.nb_blocks):
             p = f"blocks/{j}/"
-            y = b.layernorm(x, p + "norm1", eps, cite="cait.py:313")
-            qkv = b.dense(y, p + "attn/qkv/kernel", p + "attn/qkv/bias" if c.qkv_bias else None, cite="cait.py:236")
+            qkv = b.ln_dense(x, p + "norm1", eps, p + "attn/qkv/kernel", p + "attn/qkv/bias" if c.qkv_bias else None,
+                             cite_ln="cait.py:313", cite="cait.py:236")
             a = b.talking_heads_attention(qkv, nh, scale, p + "attn", cite="cait.py:237-256")
             x = b.dense(a, p + "attn/proj/kernel", p + "attn/proj/bias", out_scale=p + "gamma_1", residual=x,
                         cite="cait.py:258,314-317")
-            y = b.layernorm(x, p + "norm2", eps, cite="cait.py:320")
-            hdn = b.dense(y, p + "mlp/fc1/kernel", p + "mlp/fc1/bias", act=c.act_layer, cite="transformers.py:209-210")
+            hdn = b.ln_dense(x, p + "norm2", eps, p + "mlp/fc1/kernel", p + "mlp/fc1/bias", act=c.act_layer,
+                             cite_ln="cait.py:320", cite="transformers.py:209-210")
             x = b.dense(hdn, p + "mlp/fc2/kernel", p + "mlp/fc2/bias", out_scale=p + "gamma_2", residual=x,
                         cite="transformers.py:212, cait.py:322-325")
             if want_features:

@@ -123,8 +123,8 @@ class ConvNeXt(Model):
                 p = f"stages/{j}/blocks/{i}/"
                 y, _ = b.dwconv(x, p + "conv_dw/depthwise_kernel", stride=1, padding=3, bias=p + "conv_dw/bias",
                                 cite="convnext.py:224-225")
-                y = b.layernorm(y, p + "norm", eps, cite="convnext.py:226")
-                h = b.dense(y, p + "mlp/fc1/kernel", p + "mlp/fc1/bias", act=c.act_layer, cite="transformers.py:209-210")
+                h = b.ln_dense(y, p + "norm", eps, p + "mlp/fc1/kernel", p + "mlp/fc1/bias", act=c.act_layer,
+                               cite_ln="convnext.py:226", cite="transformers.py:209-210")
                 x = b.dense(h, p + "mlp/fc2/kernel", p + "mlp/fc2/bias", out_scale=p + "gamma", residual=x,
                             cite="transformers.py:212 + convnext.py:228-230")
                 if want_features:

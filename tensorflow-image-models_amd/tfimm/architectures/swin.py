@@ -168,13 +168,13 @@ class SwinTransformer(Model):
                 table = b.wget(p + "attn/relative_position_bias_table")
                 n = ws * ws
                 bias = table[relative_position_index(ws).reshape(-1)].reshape(n, n, nh).transpose(2, 0, 1)
-                y = b.layernorm(x, p + "norm1", eps, cite="swin.py:295")
-                qkv = b.dense(y, p + "attn/qkv/kernel", p + "attn/qkv/bias" if c.qkv_bias else None, cite="swin.py:167")
+                qkv = b.ln_dense(x, p + "norm1", eps, p + "attn/qkv/kernel", p + "attn/qkv/bias" if c.qkv_bias else None,
+                                 cite_ln="swin.py:295", cite="swin.py:167")
                 a = b.attention(qkv, nh, (D // nh) ** -0.5, window=ws, shift=shift, res=res,
                                 rel_bias=np.ascontiguousarray(bias), cite="swin.py:299-313 + 168-195", name=p + "attn")
                 x = b.dense(a, p + "attn/proj/kernel", p + "attn/proj/bias", residual=x, cite="swin.py:196,318")
-                y = b.layernorm(x, p + "norm2", eps, cite="swin.py:322")
-                hdn = b.dense(y, p + "mlp/fc1/kernel", p + "mlp/fc1/bias", act=c.act_layer, cite="transformers.py:209-210")
+                hdn = b.ln_dense(x, p + "norm2", eps, p + "mlp/fc1/kernel", p + "mlp/fc1/bias", act=c.act_layer,
+                                 cite_ln="swin.py:322", cite="transformers.py:209-210")
                 x = b.dense(hdn, p + "mlp/fc2/kernel", p + "mlp/fc2/bias", residual=x, cite="transformers.py:212, swin.py:325")
                 x.H, x.W = res
                 if want_features:

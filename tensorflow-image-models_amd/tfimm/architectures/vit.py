@@ -181,24 +181,15 @@ class ViT(Model):
             p = f"blocks/{j}/"
             # norm1 / norm2 only feed one Dense layer each: folded into it (gamma into the weights, per-row statistics
             # applied in the GEMM epilogue), so the normalised tensor is never written
-            fold = b.can_fold_ln(x)
-            if fold:
-                qkv = b.dense(x, p + "attn/qkv/kernel", p + "attn/qkv/bias" if c.qkv_bias else None,
-                              ln=(p + "norm1", eps, b.row_stats(x, eps, cite="vit.py:222")), cite="vit.py:222,155")
-            else:
-                y = b.layernorm(x, p + "norm1", eps, cite="vit.py:222")
-                qkv = b.dense(y, p + "attn/qkv/kernel", p + "attn/qkv/bias" if c.qkv_bias else None, cite="vit.py:155")
+            qkv = b.ln_dense(x, p + "norm1", eps, p + "attn/qkv/kernel", p + "attn/qkv/bias" if c.qkv_bias else None,
+                             cite_ln="vit.py:222", cite="vit.py:155")
             a = b.attention(qkv, nh, scale, cite="vit.py:156-167", name=p + "attn")
             if want_features:
                 # features["block_j/attn"]: the softmax map the fused kernel never writes (vit.py:160-163, 447-450)
                 b.p.mark_output(f"block_{j}/attn", b.attention_probs(qkv, nh, scale, cite="vit.py:160-163"))
             x = b.dense(a, p + "attn/proj/kernel", p + "attn/proj/bias", residual=x, cite="vit.py:169,228")
-            if fold:
-                hdn = b.dense(x, p + "mlp/fc1/kernel", p + "mlp/fc1/bias", act=c.act_layer,
-                              ln=(p + "norm2", eps, b.row_stats(x, eps, cite="vit.py:231")), cite="vit.py:231, transformers.py:209-210")
-            else:
-                y = b.layernorm(x, p + "norm2", eps, cite="vit.py:231")
-                hdn = b.dense(y, p + "mlp/fc1/kernel", p + "mlp/fc1/bias", act=c.act_layer, cite="transformers.py:209-210")
+            hdn = b.ln_dense(x, p + "norm2", eps, p + "mlp/fc1/kernel", p + "mlp/fc1/bias", act=c.act_layer,
+                             cite_ln="vit.py:231", cite="transformers.py:209-210")
             x = b.dense(hdn, p + "mlp/fc2/kernel", p + "mlp/fc2/bias", residual=x, cite="transformers.py:212, vit.py:234")
             if want_features:
                 b.p.mark_output(f"block_{j}", x)

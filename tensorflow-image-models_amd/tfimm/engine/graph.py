@@ -528,6 +528,15 @@ class Builder:
         """LayerNormalization over x's channels can be folded into the Dense layers that read it (dense(..., ln=...))."""
         return x.C % 8 == 0 and x.C <= 2048 and os.environ.get("TFIMM_NO_LN_FOLD", "0") != "1"
 
+    def ln_dense(self, x: TRef, ln_prefix: str, eps: float, kernel: str, bias: Optional[str] = None, *, act="",
+                 cite_ln="", cite="") -> TRef:
+        """LayerNormalization(ln_prefix) followed by a Dense layer that is its only reader: folded into one GEMM over the raw
+        rows + a statistics pass when the row width allows (``can_fold_ln``), the two launches otherwise."""
+        if self.can_fold_ln(x):
+            return self.dense(x, kernel, bias, act=act, ln=(ln_prefix, eps, self.row_stats(x, eps, cite=cite_ln)),
+                              cite=(cite_ln + ", " + cite) if cite_ln else cite)
+        return self.dense(self.layernorm(x, ln_prefix, eps, cite=cite_ln), kernel, bias, act=act, cite=cite)
+
     def row_stats(self, x: TRef, eps: float, cite="") -> TRef:
         """(mean, rstd) of every row of x -- the statistics of a LayerNormalization that is folded into its consumers."""
         st = self.p.new_tensor(x.rows, 2, dtype="f32", name="ln_stats")
