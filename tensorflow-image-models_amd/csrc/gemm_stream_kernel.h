@@ -543,7 +543,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
             rs2 = tfimm_f32x2{st[1], st[1]};
             // a real register pair: folded into the FMAs as an operand select (v_pk_fma_f32 ... op_sel:[0,1,0] on the
             // (mean, rstd) pair the ds_read_b64 returned) the LOW products came out as 0 * rstd for runs of 8 lanes, racily, on
-            // the 32-column wave tiles (tools/_lnprobe2.py: 8..20 bad launches of 20; none with the pair materialised)
+            // the 32-column wave tiles (tools/ln_tile_probe.py: 8..20 bad launches of 20; none with the pair materialised)
             asm volatile("" : "+v"(rs2));
           }
           if (TN == 2) {
