@@ -753,7 +753,8 @@ static int dw_rows_pairs_per_block(int cps, int sx) {
   return best;
 }
 
-template <int K, int S, int PX>
+// ACT >= 0: that TFIMM_ACT_* with its parameters folded into the instructions; ACT < 0: `act` from the arguments
+template <int K, int S, int PX, int DEPTH, int ACT>
 __global__ void __launch_bounds__(256) dwconv_rows_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, bf16_t* __restrict__ y,
                                                       float* sum_out, int H, int W, int C, int pad_t, int pad_l, int OH, int OW, int act,
@@ -777,7 +778,7 @@ __global__ void __launch_bounds__(256) dwconv_rows_kernel(const bf16_t* __restri
   const int cp = ct * CPB + cpl;
   const int strip = sg * SPB + sl;
   const bool live = sl < SPB && cp < cps && strip < sx;
-  const ActParams actp = make_act(act);
+  const ActParams actp = make_act(ACT >= 0 ? ACT : act);
 
   for (int i = tid; i < K * K * CPB; i += 256) {
     const int tap = i / CPB, c = i - tap * CPB;
@@ -814,21 +815,27 @@ __global__ void __launch_bounds__(256) dwconv_rows_kernel(const bf16_t* __restri
   for (int j = 0; j < NSLOT; ++j)
 #pragma unroll
     for (int px = 0; px < PX; ++px) acc[j][px] = bias2;
-  uint32_t raw[COLS];
-  load_row(r_begin, raw);
+  // two input rows in flight: one row's FMAs + activation (a few hundred cycles per wave) do not cover an HBM round trip at
+  // 4-5 waves per SIMD, two do.  The phase loop is unrolled over lcm(PERIOD, 2) so the buffer index is a compile-time constant.
+  constexpr int UNR = (DEPTH == 1 || PERIOD % 2 == 0) ? PERIOD : 2 * PERIOD;
+  uint32_t raw[DEPTH][COLS];
+  load_row(r_begin, raw[0]);
+  if (DEPTH == 2 && r_begin + 1 < r_end) load_row(r_begin + 1, raw[DEPTH - 1]);
   const tfimm_f32x2* wl = dw7_lds + cpl;
 
-  for (int rb = r_begin; rb < r_end; rb += PERIOD) {
+  for (int rb = r_begin; rb < r_end; rb += UNR) {
 #pragma unroll
-    for (int ph = 0; ph < PERIOD; ++ph) {
-      const int r = rb + ph;
+    for (int ph2 = 0; ph2 < UNR; ++ph2) {
+      constexpr int dummy_unused = 0; (void)dummy_unused;
+      const int ph = ph2 % PERIOD;
+      const int r = rb + ph2;
       if (r < r_end) {                               // wave-uniform
         tfimm_f32x2 in[COLS];
         const float rmask = (unsigned)r < (unsigned)H ? 1.f : 0.f;
 #pragma unroll
         for (int col = 0; col < COLS; ++col)
-          in[col] = (rmask * cmask[col]) * tfimm_f32x2{__uint_as_float(raw[col] << 16), __uint_as_float(raw[col] & 0xffff0000u)};
-        if (r + 1 < r_end) load_row(r + 1, raw);     // next input row in flight under this row's FMAs
+          in[col] = (rmask * cmask[col]) * tfimm_f32x2{__uint_as_float(raw[ph2 % DEPTH][col] << 16), __uint_as_float(raw[ph2 % DEPTH][col] & 0xffff0000u)};
+        if (r + DEPTH < r_end) load_row(r + DEPTH, raw[ph2 % DEPTH]);   // DEPTH rows ahead, into the buffer just consumed
         if ((unsigned)r < (unsigned)H) {
           // input row r = r_begin + ph (mod PERIOD) feeds output row oy = (r + pad_t - ky) / S for the ky of its
           // parity class (r_begin + pad_t is a multiple of S); oy lives in slot ((ph - ky) / S) mod NSLOT
@@ -854,10 +861,12 @@ __global__ void __launch_bounds__(256) dwconv_rows_kernel(const bf16_t* __restri
           const int oyd = (r + pad_t - (K - 1)) / S;
           if (r + pad_t - (K - 1) >= 0 && oyd >= oy0 && oyd < oy1) {
             bf16_t* yrow = y + ((size_t)((size_t)b * OH + oyd) * OW) * C + c0;
+            static_assert(PX == 4, "the activation runs on four packed pairs");
+            tfimm_f32x2 av[4] = {acc[dslot][0], acc[dslot][1], acc[dslot][2], acc[dslot][3]};
+            act8p(av, actp);            // packed (v_pk_*): the scalar form cost ~33 issue slots per pair for swish, this ~21
 #pragma unroll
             for (int px = 0; px < PX; ++px) {
-              const float v0 = act1(acc[dslot][px].x, actp), v1 = act1(acc[dslot][px].y, actp);
-              const uint32_t pk = pack_bf2(v0, v1);
+              const uint32_t pk = pack_bf2(av[px][0], av[px][1]);
               if (ox0 + px < OW) {
                 *reinterpret_cast<uint32_t*>(yrow + (size_t)(ox0 + px) * C) = pk;
                 // the squeeze sees the stored (bf16-rounded) activations
@@ -899,14 +908,22 @@ static int launch_dwconv_rows(const bf16_t* x, const float* w, const float* bias
   const int64_t gx = (int64_t)ctiles * sgroups * nseg;
   if (gx > 0x7fffffffLL) TFIMM_FAIL(TFIMM_EINVAL, "dwconv: grid too large");
   const size_t lds = (size_t)(K * K + 1) * CPB * sizeof(tfimm_f32x2);
-  static bool attr_done = false;
-  if (!attr_done) {
-    TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)dwconv_rows_kernel<K, S, PX>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    attr_done = true;
-  }
-  TFIMM_LAUNCH((dwconv_rows_kernel<K, S, PX>), dim3((unsigned)gx, (unsigned)B), dim3(256), lds, st, x, w, bias, y, sum_out, H, W, C,
-               pad_t, pad_l, OH, OW, act, rows_per_seg, nseg, CPB);
-  return 0;
+  // input rows in flight per thread: 2 measured slower than 1 (EfficientNet-B4 depthwise 4.68 -> 5.36 ms: the second buffer
+  // costs a wave per SIMD), TFIMM_DW_DEPTH=2 keeps it selectable for the swish flavour
+  static const int depth = getenv("TFIMM_DW_DEPTH") ? atoi(getenv("TFIMM_DW_DEPTH")) : 1;
+  auto go = [&](auto kern) -> int {
+    static bool attr_done = false;       // one flag per kernel instantiation (generic lambda)
+    if (!attr_done) {
+      TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      attr_done = true;
+    }
+    TFIMM_LAUNCH(kern, dim3((unsigned)gx, (unsigned)B), dim3(256), lds, st, x, w, bias, y, sum_out, H, W, C, pad_t, pad_l, OH, OW, act,
+                 rows_per_seg, nseg, CPB);
+    return 0;
+  };
+  if (act == TFIMM_ACT_SWISH) return depth == 2 ? go(dwconv_rows_kernel<K, S, PX, 2, TFIMM_ACT_SWISH>) : go(dwconv_rows_kernel<K, S, PX, 1, TFIMM_ACT_SWISH>);
+  if (act == TFIMM_ACT_RELU6) return go(dwconv_rows_kernel<K, S, PX, 1, TFIMM_ACT_RELU6>);
+  return go(dwconv_rows_kernel<K, S, PX, 1, -1>);
 }
 
 
