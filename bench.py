@@ -54,7 +54,7 @@ PEAK = {"hbm": (8000.0, "GB/s"), "mfma": (2500.0, "TFLOP/s")}   # MI355X_MICROAR
 ALG_BYTES_PER_IMAGE = {"resnet50": 56.8e6, "swin_base_patch4_window7_224": 140.1e6, "efficientnet_b4": 205.2e6,
                        "vit_base_patch16_224": 80.8e6, "vit_tiny_patch16_224": 20.4e6}
 FAMILY_KERNELS = {"gemm": "tfimm_gemm::* (every GEMM / convolution flavour, incl. the fused bottleneck tail) + stem_pool_kernel",
-                  "attention": "attn_*_kernel", "dwconv": "dwconv_*_kernel"}
+                  "attention": "attn_*_kernel", "dwconv": "dwconv_*_kernel + expand_dw_kernel (fused expansion + depthwise)"}
 
 
 def parse():
@@ -205,8 +205,8 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
                 eager_ms_per_step=None if eager_dt is None else eager_dt / steps * 1e3)
 
 
-_EVENT_KINDS = {"gemm": "gemm", "stem_pool": "gemm", "conv_chain": "gemm", "dwconv": "dwconv", "attention": "attention",
-                "talking_heads_attention": "attention"}
+_EVENT_KINDS = {"gemm": "gemm", "stem_pool": "gemm", "conv_chain": "gemm", "grouped_conv": "gemm", "dwconv": "dwconv",
+                "expand_dwconv": "dwconv", "attention": "attention", "talking_heads_attention": "attention"}
 
 
 def run_with_events(plan, x_dev, events):
@@ -223,7 +223,8 @@ def run_with_events(plan, x_dev, events):
     from tfimm.engine.graph import _hip_memset_async
     B = plan.batch
     by_fn = {id(lib.tfimm_hip_gemm): "gemm", id(lib.tfimm_hip_stem_conv_pool): "stem_pool",
-             id(lib.tfimm_hip_conv_chain): "conv_chain",
+             id(lib.tfimm_hip_conv_chain): "conv_chain", id(lib.tfimm_hip_grouped_conv3x3): "grouped_conv",
+             id(lib.tfimm_hip_expand_dwconv): "expand_dwconv",
              id(lib.tfimm_hip_dwconv): "dwconv", id(lib.tfimm_hip_attention): "attention",
              id(lib.tfimm_hip_talking_heads_attention): "talking_heads_attention"}     # ctypes functions are not hashable
     cache = plan.__dict__.setdefault("_timed_ops", {})
