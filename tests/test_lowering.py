@@ -200,3 +200,39 @@ def test_narrow_mbconv_fronts_are_one_launch(monkeypatch):
     monkeypatch.setenv("TFIMM_NO_MBCONV_FUSION", "1")
     kinds2, prog2 = _kinds("efficientnet_b0")
     assert "expand_dwconv" not in kinds2 and len(kinds2) == len(kinds) + 3 and prog2.flops_per_image() == flops
+
+
+def test_layernorms_with_one_dense_reader_are_folded(monkeypatch):
+    """norm1 -> qkv and norm2 -> fc1 lower to a statistics pass + ONE GEMM over the raw rows (gamma in the weights, beta . W in
+    the bias, column sums of the rounded weights as correction fragments); only the final norm stays a LayerNorm launch;
+    TFIMM_NO_LN_FOLD=1 keeps the LayerNorm launches"""
+    import numpy as np
+    from tfimm.engine import pack
+    kinds, prog = _kinds("vit_tiny_patch16_224")
+    assert kinds.count("row_stats") == 24 and kinds.count("layernorm") == 1
+    folded = [op for op in prog.ops if op.kind == "gemm" and op.attrs.get("ln")]
+    assert len(folded) == 24 and all(len(op.inputs) == 2 and "ln_c1" in op.consts for op in folded)
+    op = folded[0]
+    m = tfimm.create_model("vit_tiny_patch16_224")
+    w = synthetic_weights(m)
+    m.set_weights(w)
+    g, bt = w["blocks/0/norm1/gamma"], w["blocks/0/norm1/beta"]
+    k, b = w["blocks/0/attn/qkv/kernel"], w["blocks/0/attn/qkv/bias"]
+    wt = prog.consts[op.consts["wt"]].host
+    np.testing.assert_array_equal(wt[:, :192], pack.to_bf16_bits((k * g[:, None]).T))
+    np.testing.assert_allclose(prog.consts[op.consts["bias"]].host, bt @ k + b, rtol=1e-5, atol=1e-6)
+    c1 = prog.consts[op.consts["ln_c1"]].host                    # [N][2][8]: {ca,cb,cc,ca,cb,cc,ca,cb} {cc,0,...}
+    terms = pack.bf16_bits_to_f32(c1[:, 0, :3]).astype(np.float64).sum(1)
+    np.testing.assert_allclose(terms, pack.bf16_bits_to_f32(wt[:, :192]).astype(np.float64).sum(1), rtol=2e-7, atol=1e-7)
+    assert (c1[:, 0, 3:6] == c1[:, 0, :3]).all() and (c1[:, 1, 0] == c1[:, 0, 2]).all() and not c1[:, 1, 1:].any()
+    monkeypatch.setenv("TFIMM_NO_LN_FOLD", "1")
+    kinds2, _ = _kinds("vit_tiny_patch16_224")
+    assert "row_stats" not in kinds2 and kinds2.count("layernorm") == 25
+
+
+def test_three_way_bf16_split_is_exact_to_24_bits():
+    import numpy as np
+    from tfimm.engine import pack
+    v = np.random.default_rng(0).standard_normal(1000).astype(np.float32) * np.float32(37.0)
+    t = pack.bf16_bits_to_f32(pack.split3_bf16(v)).astype(np.float64)
+    assert np.abs(t.sum(-1) - v.astype(np.float64)).max() <= np.abs(v).max() * 2.0 ** -23
