@@ -769,6 +769,155 @@ __global__ void __launch_bounds__(NW * 64) attn_stream_kernel(const AttnArgs p, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Swin window attention, several heads per workgroup (hd = 32, n <= 64 tokens per window, pre-combined bias tiles).
+// attn_resident_kernel runs one (window, head) per workgroup: 16384 workgroups of ~5 us for a Swin-B stage-3 layer, each
+// a serial chain (index map -> Q / K / V loads -> LDS -> scores -> softmax -> P.V -> store) whose loads nothing overlaps, and
+// the roll / window_partition index map is recomputed for each of a window's heads.  Here a workgroup owns a window and a
+// RANGE of its heads: the index map is computed once, and while head h is being multiplied out of LDS the Q fragment and
+// the one K and one V chunk each thread stages for head h + 1 are already on their way into registers (12 VGPRs), written
+// to LDS behind the barrier that ends head h.  Same arithmetic, same LDS layouts and the same transposing V reads as the
+// resident kernel (TQ = 1: a wave owns one 16-query tile).
+template <int HD>
+__global__ void __launch_bounds__(256) attn_window_kernel(const AttnArgs p, const int hsplit) {
+  constexpr int NT = 256, NW = 4;
+  constexpr int CH = HD / 8, KROW = CH + 1, DT = HD / 16;
+  static_assert(HD == 32, "window kernel: head dim 32");
+  constexpr int NKP = 64;
+  constexpr float LOG2E = 1.4426950408889634f;
+  __shared__ __attribute__((aligned(16))) uint4 Ks[NKP * KROW];
+  __shared__ __attribute__((aligned(16))) uint4 Vs[NKP * CH];
+  __shared__ int Rw[NKP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  int item = blockIdx.x;
+  {   // XCD-contiguous ranges, as in the resident kernel
+    const int G = (int)gridDim.x, xcd = item & 7, idx = item >> 3;
+    item = xcd * (G >> 3) + min(xcd, G & 7) + idx;
+  }
+  const int seq = item / hsplit, part = item - seq * hsplit;
+  const int hpw = p.heads / hsplit;
+  const int h0 = part * hpw, h1 = h0 + hpw;
+
+  if (tid < NKP) {
+    int rg;
+    Rw[tid] = tid < p.n ? (int)token_row<true>(p, seq, tid, &rg) : 0;
+  }
+  __syncthreads();
+  const int qi = wave * 16 + l15;
+  const bool q_ok = qi < p.n;
+  const int64_t q_row = Rw[q_ok ? qi : 0];
+  // staging role of this thread: key row tid / CH, chunk tid % CH of K and of V (NKP * CH == NT)
+  const int skey = tid / CH, sc8 = tid - skey * CH;
+  const bool s_ok = skey < p.n;
+  const bf16_t* srow = p.qkv + (int64_t)Rw[s_ok ? skey : 0] * p.ld + sc8 * 8;
+  const bf16_t* qrow = p.qkv + q_row * p.ld + g * 8;
+  const int w = seq % p.nw;
+  const int wy = w / p.nwx, wx = w - wy * p.nwx;
+  const int kind = p.shift > 0 ? 2 * (wy == p.nw / p.nwx - 1 ? 1 : 0) + (wx == p.nwx - 1 ? 1 : 0) : 0;
+  const float cs = p.scale * LOG2E;
+
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  u32x4 kreg, vreg, qreg;
+  float4 breg[4];                                  // this lane's (bias + mask) * log2e values of the next head's score block
+  const float* bbase = p.bias_log2 + ((size_t)kind * p.heads * p.n + (q_ok ? qi : 0)) * NKP + g * 4;
+  auto fetch = [&](int h) __attribute__((always_inline)) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    kreg = s_ok ? *reinterpret_cast<const u32x4*>(srow + p.dmodel + h * HD) : z;
+    vreg = s_ok ? *reinterpret_cast<const u32x4*>(srow + 2 * p.dmodel + h * HD) : z;
+    qreg = q_ok ? *reinterpret_cast<const u32x4*>(qrow + h * HD) : z;
+    const float* bl = bbase + (size_t)h * p.n * NKP;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) breg[t] = *reinterpret_cast<const float4*>(bl + t * 16);
+  };
+  fetch(h0);
+  for (int h = h0; h < h1; ++h) {
+    reinterpret_cast<u32x4*>(Ks)[k_slot<HD>(skey, sc8)] = kreg;
+    reinterpret_cast<u32x4*>(Vs)[v_slot<HD>(skey, sc8)] = vreg;
+    const bf16x8 qf = __builtin_bit_cast(bf16x8, qreg);
+    const float4 bq[4] = {breg[0], breg[1], breg[2], breg[3]};
+    __syncthreads();
+    if (h + 1 < h1) fetch(h + 1);                 // in flight under this head's arithmetic
+    if (wave * 16 < p.n) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const bf16x8 kf = __builtin_bit_cast(bf16x8, Ks[k_slot<HD>(t * 16 + l15, g)]);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, acc[t], 0, 0, 0);
+      }
+      float sc[16];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float4 b4 = bq[t];
+        sc[t * 4 + 0] = fmaf(acc[t][0], cs, b4.x); sc[t * 4 + 1] = fmaf(acc[t][1], cs, b4.y);
+        sc[t * 4 + 2] = fmaf(acc[t][2], cs, b4.z); sc[t * 4 + 3] = fmaf(acc[t][3], cs, b4.w);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (t * 16 + g * 4 + r >= p.n) sc[t * 4 + r] = -__builtin_inff();
+      float mloc = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+#pragma unroll
+      for (int i = 3; i < 15; i += 2) mloc = fmaxf(fmaxf(mloc, sc[i]), sc[i + 1]);
+      mloc = fmaxf(mloc, sc[15]);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      float psum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        sc[i] = __builtin_amdgcn_exp2f(sc[i] - mloc);
+        psum += sc[i];
+      }
+      bf16x8 pf[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        uint4 pu;
+        pu.x = pack_bf2(sc[8 * s2 + 0], sc[8 * s2 + 1]);
+        pu.y = pack_bf2(sc[8 * s2 + 2], sc[8 * s2 + 3]);
+        pu.z = pack_bf2(sc[8 * s2 + 4], sc[8 * s2 + 5]);
+        pu.w = pack_bf2(sc[8 * s2 + 6], sc[8 * s2 + 7]);
+        pf[s2] = __builtin_bit_cast(bf16x8, pu);
+      }
+      f32x4 o[DT];
+#pragma unroll
+      for (int i = 0; i < DT; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      typedef __attribute__((ext_vector_type(4))) short s16x4;
+      typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int krow = g * 4 + (l15 >> 2);
+          const int chunk = dt * 2 + ((l15 & 3) >> 1);
+          const char* base = reinterpret_cast<const char*>(Vs) + (l15 & 1) * 8;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (lds_s16x4_ptr)(base + (size_t)v_slot<HD>(krow + (2 * s2) * 16, chunk) * 16));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (lds_s16x4_ptr)(base + (size_t)v_slot<HD>(krow + (2 * s2 + 1) * 16, chunk) * 16));
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cat), pf[s2], o[dt], 0, 0, 0);
+        }
+      }
+      float l_tot = psum + __shfl_xor(psum, 16, 64);
+      l_tot += __shfl_xor(l_tot, 32, 64);
+      if (q_ok) {
+        const float inv = 1.f / l_tot;
+        bf16_t* op = p.out + q_row * p.dmodel + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int d0 = dt * 16 + g * 4;
+          *reinterpret_cast<uint2*>(op + d0) =
+              make_uint2(pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv));
+        }
+      }
+    }
+    __syncthreads();                              // every wave is done with this head's K / V
+  }
+}
+
 template <int HD, int NW, int TQ>
 static int launch_attn_stream(const AttnArgs& a, int64_t nseq, hipStream_t st) {
   const int nkp = (a.n + 63) / 64 * 64;
@@ -875,6 +1024,17 @@ extern "C" int tfimm_hip_attention(const tfimm_attn_desc* dp, void* stream) {
     if (use_resident && !no_stream && d.window == 0 && a.vec && a.n > 128 && a.n <= 256 && d.hd == 64 &&
         nseq * d.heads >= 2048 && nseq * d.heads <= 0x7fffffffLL)
       return launch_attn_stream<64, 16, 1>(a, nseq, st);
+    // Swin windows (head dim 32, <= 64 tokens, pre-combined bias tiles): a workgroup owns a window and a range of its heads
+    static const bool no_window = getenv("TFIMM_ATTN_NO_WINDOW") != nullptr;
+    if (use_resident && !no_window && tl && a.vec && d.hd == 32 && a.n <= 64 && nseq * d.heads <= 0x7fffffffLL) {
+      // heads per workgroup: split a window's heads over workgroups until there are ~16 workgroups per CU (measured on Swin-B:
+      // 2.00 ms of attention at a 1024-workgroup threshold, 1.93 at 4096)
+      int hsplit = 1;
+      static const int64_t win_wgs = getenv("TFIMM_ATTN_WIN_WGS") ? atoi(getenv("TFIMM_ATTN_WIN_WGS")) : 4096;
+      while (hsplit < d.heads && nseq * hsplit < win_wgs && d.heads % (hsplit * 2) == 0) hsplit *= 2;
+      TFIMM_LAUNCH((attn_window_kernel<32>), dim3((unsigned)(nseq * hsplit)), dim3(256), 0, st, a, hsplit);
+      return 0;
+    }
     if (use_resident && lds <= 80 * 1024 && a.n <= 256 && nseq * d.heads <= 0x7fffffffLL) {
       if (d.window > 0)
         return d.hd <= 32 ? launch_attn_resident_any<32, true>(a, nseq, st) : launch_attn_resident_any<64, true>(a, nseq, st);
