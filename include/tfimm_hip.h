@@ -397,6 +397,13 @@ typedef struct tfimm_expand_dw_desc {
   float* sum_out;
   int32_t B, H, W, Cin, C, Cpad, k, stride, pad_t, pad_l, OH, OW;
   int32_t act1, act2;
+  int32_t stem;           /* 1: the "expansion" is the network's 3 x 3 / stride 2 RGB stem convolution (conv_stem + bn1 + act,
+                             efficientnet.py:300-302) in front of the first block's depthwise layer: x is the zero-bordered
+                             4-channel image [B][img_h][img_w][4] of tfimm_hip_cast_input_pad (the convolution itself pads
+                             nothing), Cin = 4, H x W the convolution's OUTPUT size, k = 3 / stride = 1 the depthwise layer,
+                             and w1 is bf16 [Cpad/32][3][64][8] with element [cc][ks][lane][j] = W[tap][c][32 cc + (lane & 31)],
+                             tap = 4 ks + 2 (lane >> 5) + j / 4, c = j % 4 (zero for tap >= 9, c >= 3) */
+  int32_t img_h, img_w;
 } tfimm_expand_dw_desc;
 
 TFIMM_API int tfimm_hip_expand_dwconv(const tfimm_expand_dw_desc* d, void* stream);

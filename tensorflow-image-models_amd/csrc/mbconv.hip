@@ -33,10 +33,11 @@ struct MbArgs {
   bf16_t* y;
   float* sums;
   int H, W, Cin, C, Cpad, pad_t, pad_l, OH, OW, tiles_x, act1, act2;
+  int img_h, img_w;   // STEM: the padded 4-channel image x points at; H, W are then the convolution's output (= depthwise input) size
   int dbg;      // TFIMM_MB_DBG ablation bits: 1 no output stores, 2 no phase-2 activation, 4 no phase-1 activation
 };
 
-template <int K, int S, int OTH, int OTW>
+template <int K, int S, int OTH, int OTW, bool STEM = false>
 struct MbGeom {
   static constexpr int NT = 512, NSLOT = 32;
   static constexpr int RG = NSLOT / OTW, RPT = OTH / RG;
@@ -45,7 +46,11 @@ struct MbGeom {
   static constexpr int JB = (NBLK + 7) / 8;
   static constexpr int NR = (RPT - 1) * S + K;
   static constexpr int XP = 64, EP = 72;
-  static constexpr int X_BYTES = NPX * XP, E_BYTES = NPX * EP;
+  // STEM: the expansion is a 3 x 3 / stride 2 convolution of the padded 4-channel image; LDS holds the image region the halo
+  // needs ((2 IH + 1) x (2 IW + 1) pixels of 8 bytes) instead of the halo's own pixels
+  static constexpr int XIH = 2 * IH + 1, XIW = 2 * IW + 1;
+  static constexpr int X_BYTES = STEM ? (XIH * XIW * 8 + 15) / 16 * 16 : NPX * XP, E_BYTES = NPX * EP;
+  static constexpr int KS = STEM ? 3 : 2;                      // MFMA k-steps of the expansion (K padded to 48 / 32)
   static constexpr int WD_FLOATS = (K * K + 1) * 32;
   static constexpr int LDS = X_BYTES + E_BYTES + WD_FLOATS * 4 + 64 * 4;
   static_assert(LDS <= 80 * 1024, "two workgroups per CU");
@@ -53,9 +58,9 @@ struct MbGeom {
 
 // ACT >= 0: both activations are that TFIMM_ACT_* (its parameters fold into the instructions: no scalar registers, no class
 // branches); ACT < 0: read act1 / act2 from the arguments
-template <int K, int S, int OTH, int OTW, int ACT>
+template <int K, int S, int OTH, int OTW, int ACT, bool STEM = false>
 __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
-  using G = MbGeom<K, S, OTH, OTW>;
+  using G = MbGeom<K, S, OTH, OTW, STEM>;
   extern __shared__ __attribute__((aligned(16))) unsigned char mb_smem[];
   unsigned char* Xs = mb_smem;
   unsigned char* Es = mb_smem + G::X_BYTES;
@@ -68,7 +73,19 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
   const int gy0 = oy0 * S - p.pad_t, gx0 = ox0 * S - p.pad_l;
 
   // ---- phase 0: the input halo, once per tile ------------------------------------------------------------------------
-  {
+  if (STEM) {
+    // image rows 2 (gy0 + iy) + ky, columns 2 (gx0 + ix) + kx: the region starts at (2 gy0, 2 gx0)
+    const bf16_t* xb = p.x + (size_t)b * p.img_h * p.img_w * 4;
+    for (int i = tid; i < G::XIH * G::XIW; i += G::NT) {
+      const int y = i / G::XIW, xx = i - y * G::XIW;
+      const int gy = 2 * gy0 + y, gx = 2 * gx0 + xx;
+      uint2 v = make_uint2(0u, 0u);
+      if ((unsigned)gy < (unsigned)p.img_h && (unsigned)gx < (unsigned)p.img_w)
+        v = *reinterpret_cast<const uint2*>(xb + ((size_t)gy * p.img_w + gx) * 4);
+      *reinterpret_cast<uint2*>(Xs + i * 8) = v;
+    }
+    if (tid < 64) lsum[tid] = 0.f;
+  } else {
     const int nch = p.Cin >> 3;
     const bf16_t* xb = p.x + (size_t)b * p.H * p.W * p.Cin;
 #pragma unroll
@@ -112,9 +129,9 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
       lsum[h] = 0.f;
     }
     // ---- phase 1: expand + activation into LDS ------------------------------------------------------------------------
-    bf16x8 af[2];
+    bf16x8 af[G::KS];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) af[ks] = __builtin_bit_cast(bf16x8, p.w1[(size_t)(cc * 2 + ks) * 64 + lane]);
+    for (int ks = 0; ks < G::KS; ++ks) af[ks] = __builtin_bit_cast(bf16x8, p.w1[(size_t)(cc * G::KS + ks) * 64 + lane]);
     f32x4 bq[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -136,15 +153,39 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
       if (blk < G::NBLK) {
         const int px = blk * 32 + l31;
         const int pxr = min(px, G::NPX - 1);
-        const int sw = (pxr >> 2) & 3;
-        const unsigned char* xa = Xs + pxr * G::XP;
-        const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(xa + ((hi ^ sw) << 4));
-        const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(xa + (((2 + hi) ^ sw) << 4));
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], x0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], x1, acc, 0, 0, 0);
+        if (STEM) {
+          // k = 4 tap + channel: this lane's half of k-step ks holds taps 4 ks + 2 hi and + 1 (ky = tap / 3, kx = tap % 3;
+          // taps 9..11 do not exist), 8 bytes each out of the image region
+          const int py = pxr / G::IW, pxx = pxr - py * G::IW;
+          const unsigned char* xa = Xs + ((2 * py) * G::XIW + 2 * pxx) * 8;
+#pragma unroll
+          for (int ks = 0; ks < G::KS; ++ks) {
+            uint2 t[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              t[e] = make_uint2(0u, 0u);
+              if (ks < 2) {                                                  // taps 0..7: both halves exist
+                const int tap = ks * 4 + hi * 2 + e;
+                t[e] = *reinterpret_cast<const uint2*>(xa + ((tap / 3) * G::XIW + tap % 3) * 8);
+              } else if (e == 0) {                                           // k-step 2: tap 8 (hi == 0) only
+                const uint2 v = *reinterpret_cast<const uint2*>(xa + (2 * G::XIW + 2) * 8);
+                t[e] = hi ? make_uint2(0u, 0u) : v;
+              }
+            }
+            const uint4 u = make_uint4(t[0].x, t[0].y, t[1].x, t[1].y);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], __builtin_bit_cast(bf16x8, u), acc, 0, 0, 0);
+          }
+        } else {
+          const int sw = (pxr >> 2) & 3;
+          const unsigned char* xa = Xs + pxr * G::XP;
+          const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(xa + ((hi ^ sw) << 4));
+          const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(xa + (((2 + hi) ^ sw) << 4));
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], x0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[G::KS > 1 ? 1 : 0], x1, acc, 0, 0, 0);
+        }
         const uint32_t keep = ((vbits >> j) & 1u) ? 0xffffffffu : 0u;
         unsigned char* ea = Es + px * G::EP + hi * 8;
 #pragma unroll
@@ -233,13 +274,13 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
   }
 }
 
-template <int K, int S, int OTH, int OTW, int ACT>
+template <int K, int S, int OTH, int OTW, int ACT, bool STEM = false>
 int launch_expand_dw_act(const MbArgs& a0, int B, hipStream_t st) {
-  using G = MbGeom<K, S, OTH, OTW>;
+  using G = MbGeom<K, S, OTH, OTW, STEM>;
   MbArgs a = a0;
   a.tiles_x = (a.OW + OTW - 1) / OTW;
   const int tiles_y = (a.OH + OTH - 1) / OTH;
-  auto fn = expand_dw_kernel<K, S, OTH, OTW, ACT>;
+  auto fn = expand_dw_kernel<K, S, OTH, OTW, ACT, STEM>;
   static bool ready = false;
   if (!ready) {
     TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
@@ -263,7 +304,12 @@ extern "C" int tfimm_hip_expand_dwconv(const tfimm_expand_dw_desc* d, void* stre
   if (!d->x || !d->w1 || !d->b1 || !d->wdw || !d->b2 || !d->y) TFIMM_FAIL(TFIMM_EINVAL, "expand_dwconv: null pointer");
   if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->OH <= 0 || d->OW <= 0)
     TFIMM_FAIL(TFIMM_EINVAL, "expand_dwconv: bad shape");
-  if (d->Cin <= 0 || (d->Cin & 7) || d->Cin > 32)
+  if (d->stem) {
+    // x is the zero-bordered 4-channel image; the expansion is the 3 x 3 / stride 2 stem convolution without padding of its own
+    if (d->Cin != 4 || d->img_h <= 0 || d->img_w <= 0 || 2 * (d->H - 1) + 3 > d->img_h || 2 * (d->W - 1) + 3 > d->img_w)
+      TFIMM_FAIL(TFIMM_EINVAL, "expand_dwconv: stem needs Cin = 4 and an image of at least %d x %d pixels", 2 * d->H + 1, 2 * d->W + 1);
+    if (d->k != 3 || d->stride != 1) TFIMM_FAIL(TFIMM_EUNSUP, "expand_dwconv: stem flavour is built for a 3 x 3 / stride 1 depthwise layer");
+  } else if (d->Cin <= 0 || (d->Cin & 7) || d->Cin > 32)
     TFIMM_FAIL(TFIMM_EUNSUP, "expand_dwconv: Cin=%d (multiples of 8 up to 32)", d->Cin);
   if ((d->C & 1) || d->Cpad != (d->C + 31) / 32 * 32)
     TFIMM_FAIL(TFIMM_EINVAL, "expand_dwconv: C=%d must be even and Cpad=%d its multiple-of-32 ceiling", d->C, d->Cpad);
@@ -279,9 +325,15 @@ extern "C" int tfimm_hip_expand_dwconv(const tfimm_expand_dw_desc* d, void* stre
   a.y = (bf16_t*)d->y; a.sums = d->sum_out;
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.C = d->C; a.Cpad = d->Cpad; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
   a.OH = d->OH; a.OW = d->OW; a.tiles_x = 0; a.act1 = d->act1; a.act2 = d->act2;
+  a.img_h = d->img_h; a.img_w = d->img_w;
   static const int dbg = getenv("TFIMM_MB_DBG") ? atoi(getenv("TFIMM_MB_DBG")) : 0;
   a.dbg = dbg;
   hipStream_t st = (hipStream_t)stream;
+  if (d->stem) {
+    if (a.act1 == a.act2 && a.act1 == TFIMM_ACT_SWISH) return launch_expand_dw_act<3, 1, 12, 32, TFIMM_ACT_SWISH, true>(a, d->B, st);
+    if (a.act1 == a.act2 && a.act1 == TFIMM_ACT_RELU6) return launch_expand_dw_act<3, 1, 12, 32, TFIMM_ACT_RELU6, true>(a, d->B, st);
+    return launch_expand_dw_act<3, 1, 12, 32, -1, true>(a, d->B, st);
+  }
   if (d->k == 3 && d->stride == 1) return launch_expand_dw<3, 1, 12, 32>(a, d->B, st);
   if (d->k == 3 && d->stride == 2) return launch_expand_dw<3, 2, 8, 16>(a, d->B, st);
   if (d->k == 5 && d->stride == 2) return launch_expand_dw<5, 2, 6, 16>(a, d->B, st);

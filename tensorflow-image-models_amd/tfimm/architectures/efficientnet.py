@@ -304,15 +304,27 @@ class EfficientNet(Model):
             return 0
 
         x = b.image_input(H, W, c.in_channels)
-        x = b.conv(x, "conv_stem/kernel", stride=2, padding=pad(3, 2), bn="bn1", bn_eps=eps, act=c.act_layer,
-                   cite="efficientnet.py:300-302")
+        plans = self.block_plans()
+        # stem + the first block's depthwise layer as one launch when nothing else reads the stem output: a depthwise-separable
+        # first block that takes no shortcut from the stem, and no "stem" feature requested
+        stem_fused = None
+        first = plans[0] if plans else None
+        if (first is not None and first.type == "ds" and first.k == 3 and first.stride == 1 and not first.skip
+                and not want_features and c.act_layer == first.act):
+            stem_fused = b.stem_dwconv(x, "conv_stem/kernel", "bn1", first.name + "/conv_dw/depthwise_kernel",
+                                       first.name + "/bn1", bn_eps=eps, padding=pad(3, 2), dw_padding=pad(3, 1),
+                                       act=c.act_layer, squeeze=first.rd > 0,
+                                       cite="efficientnet.py:300-302, efficientnet_blocks.py:350-352")
+        if stem_fused is None:
+            x = b.conv(x, "conv_stem/kernel", stride=2, padding=pad(3, 2), bn="bn1", bn_eps=eps, act=c.act_layer,
+                       cite="efficientnet.py:300-302")
         if want_features:
             b.p.mark_output("stem", x)
-        for blk in self.block_plans():
+        for blk in plans:
             p = blk.name
             shortcut = x if blk.skip else None
             if blk.type in ("ds", "ir"):
-                fused = None
+                fused = stem_fused if blk is first else None
                 if blk.type == "ir":
                     dw_bn, proj, proj_bn, proj_act = p + "/bn2", p + "/conv_pwl/kernel", p + "/bn3", ""
                     # narrow inputs (the first stages): expansion + depthwise as one launch, the expanded tensor stays in LDS

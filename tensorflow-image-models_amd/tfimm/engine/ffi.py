@@ -88,6 +88,7 @@ class ExpandDwDesc(C.Structure):
         ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("C", C.c_int32), ("Cpad", C.c_int32),
         ("k", C.c_int32), ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32), ("OH", C.c_int32),
         ("OW", C.c_int32), ("act1", C.c_int32), ("act2", C.c_int32),
+        ("stem", C.c_int32), ("img_h", C.c_int32), ("img_w", C.c_int32),
     ]
 
 

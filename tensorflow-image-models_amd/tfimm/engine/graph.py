@@ -725,6 +725,56 @@ class Builder:
               flops=2 * x.H * x.W * cin * c + 2 * OH * OW * c * kh * kw)
         return out, sums
 
+    def stem_dwconv(self, x: TRef, stem_kernel: str, stem_bn: str, dw_kernel: str, dw_bn: str, *, bn_eps=1e-5, stride=2,
+                    padding="same", dw_padding="same", act="", squeeze=False, cite=""):
+        """RGB stem (3x3 / stride 2 Conv2D + BN + act) followed by the first block's depthwise 3x3 / stride 1 + BN + act as ONE
+        launch (tfimm_hip_expand_dwconv, stem flavour): the stem's output -- at 190 x 190 x 48 the second largest tensor of
+        EfficientNet-B4 -- never reaches HBM.  ``x`` must be the (still unpadded) 4-channel output of the input cast; its zero
+        border is set here the way ``conv`` does for the pixel-pair view.  None when the shape is not what that kernel is built
+        for; otherwise (output, squeeze sums or None)."""
+        p = self.p
+        ks, kd = self.wget(stem_kernel), self.wget(dw_kernel)
+        kh, kw, cin, c = ks.shape
+        if (x.C != 4 or getattr(self, "_cast_out", None) != x.id or self._cast_op.attrs["pad"] != (0, 0, 0, 0)
+                or self._cast_op.attrs.get("used") or (kh, kw) != (3, 3) or stride != 2 or cin > 4 or c % 2
+                or kd.shape != (3, 3, c, 1) or os.environ.get("TFIMM_NO_MBCONV_FUSION", "0") == "1"):
+            return None
+        if padding == "same":
+            SH, pt, _ = same_padding(x.H, 3, 2)
+            SW, pl, _ = same_padding(x.W, 3, 2)
+        else:
+            pt = pl = int(padding)
+            SH, SW = (x.H + 2 * pt - 3) // 2 + 1, (x.W + 2 * pl - 3) // 2 + 1
+        if dw_padding == "same":
+            OH, dpt, _ = same_padding(SH, 3, 1)
+            OW, dpl, _ = same_padding(SW, 3, 1)
+        else:
+            dpt = dpl = int(dw_padding)
+            OH, OW = SH + 2 * dpt - 2, SW + 2 * dpl - 2
+        hp, wp = max(x.H + pt, (SH - 1) * 2 + 3), max(x.W + pl, (SW - 1) * 2 + 3)
+        self._cast_op.attrs.update(pad=(pt, hp - x.H - pt, pl, wp - x.W - pl), used=True)
+        xt = p.tensors[x.id]
+        xt.rows, xt.H, xt.W = hp * wp, hp, wp
+        cpad = pack.ceil_to(c, 32)
+        s1, t1 = self.bn(stem_bn, bn_eps)
+        s2, t2 = self.bn(dw_bn, bn_eps)
+        w1 = pack.pack_stem_frag(ks.astype(np.float32) * s1.reshape(1, 1, 1, c), cpad)
+        wd, b2 = pack.pack_depthwise(kd, s2, t2)
+
+        def padc(a):
+            out = np.zeros(a.shape[:-1] + (cpad,), np.float32)
+            out[..., :c] = a
+            return out
+        consts = {"w1": p.new_const(w1, stem_kernel + ":frag"), "b1": p.new_const(padc(np.asarray(t1, np.float32)), stem_kernel + ":bias"),
+                  "wdw": p.new_const(padc(wd), dw_kernel + ":pad"), "b2": p.new_const(padc(b2), dw_kernel + ":bias")}
+        out = p.new_tensor(OH * OW, c, OH, OW, name=dw_kernel)
+        sums = p.new_tensor(1, c, dtype="f32", name=dw_kernel + ":sums") if squeeze else None
+        p.add("expand_dwconv", [x], out, consts, cite=cite, extra_outputs=[sums] if sums is not None else [],
+              H=SH, W=SW, Cin=4, C=c, Cpad=cpad, k=3, stride=1, pad_t=dpt, pad_l=dpl, OH=OH, OW=OW, act=act,
+              sums=None if sums is None else sums.id, stem=1, img_h=hp, img_w=wp,
+              flops=2 * SH * SW * 9 * cin * c + 2 * OH * OW * c * 9)
+        return out, sums
+
     def se_gate(self, sums: TRef, count: int, w_reduce: str, b_reduce: str, w_expand: str, b_expand: str,
                 act: str, gate_act="sigmoid", cite="") -> TRef:
         p = self.p
@@ -948,6 +998,7 @@ class Plan:
                 d.B, d.H, d.W, d.Cin, d.C, d.Cpad = B, a["H"], a["W"], a["Cin"], a["C"], a["Cpad"]
                 d.k, d.stride, d.pad_t, d.pad_l, d.OH, d.OW = a["k"], a["stride"], a["pad_t"], a["pad_l"], a["OH"], a["OW"]
                 d.act1 = d.act2 = ffi.ACT[a["act"]]
+                d.stem, d.img_h, d.img_w = a.get("stem", 0), a.get("img_h", 0), a.get("img_w", 0)
                 self._keepalive.append(d)
                 self.calls.append((lib.tfimm_hip_expand_dwconv, (C.byref(d),)))
             elif k == "grouped_conv":

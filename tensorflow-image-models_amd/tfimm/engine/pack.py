@@ -195,3 +195,19 @@ def pack_ln_c1(wt_bits: np.ndarray, n: int, k: int) -> np.ndarray:
     out[:, 0, :] = t[:, [0, 1, 2, 0, 1, 2, 0, 1]]
     out[:, 1, 0] = t[:, 2]
     return out
+
+
+def pack_stem_frag(kernel: np.ndarray, cpad: int) -> np.ndarray:
+    """3 x 3 stem kernel (3, 3, cin <= 4, C) (BN scale folded) as the MFMA A fragments of tfimm_hip_expand_dwconv's stem
+    flavour: uint16 [cpad/32][3][64][8], element [cc][ks][lane][j] = kernel[tap // 3][tap % 3][j % 4][32 cc + (lane & 31)]
+    with tap = 4 ks + 2 (lane >> 5) + j // 4 (zero for tap >= 9, channels the kernel does not have, columns >= C)."""
+    kh, kw, cin, c = kernel.shape
+    assert (kh, kw) == (3, 3) and cin <= 4 and cpad % 32 == 0 and cpad >= c
+    full = np.zeros((12, 4, cpad), np.float32)                     # [tap][channel][column]
+    full[:9, :cin, :c] = kernel.reshape(9, cin, c)
+    lane = np.arange(64)
+    j = np.arange(8)
+    tap = 4 * np.arange(3)[:, None, None] + 2 * (lane >> 5)[None, :, None] + (j // 4)[None, None, :]       # [3][64][8]
+    ch4 = np.broadcast_to((j % 4)[None, None, :], tap.shape)
+    col = 32 * np.arange(cpad // 32)[:, None, None, None] + (lane & 31)[None, None, :, None]                # [cc][1][64][1]
+    return to_bf16_bits(full[tap[None], ch4[None], col])

@@ -793,6 +793,50 @@ CASES["ln_gemm_one_k_tile"] = lambda: _ln_gemm_case(5000, 32, 96, "", 349, offse
 CASES["ln_gemm_multi_round"] = lambda: _ln_gemm_case(70000, 128, 256, "", 348, offset=1.0)
 
 
+def _stem_dw_case(B, H, W, cin, c, act, seed, padding="same"):
+    """stem flavour of tfimm_hip_expand_dwconv: 3x3 / stride 2 convolution of the RGB image + act (rounded to bf16) followed by
+    a 3x3 depthwise layer + act, against the same two layers in fp32"""
+    import hip_ops as Hh
+    r = _rng(seed)
+    x = _bf(r.standard_normal((B, H, W, cin)))
+    ks = (r.standard_normal((3, 3, cin, c)) / math.sqrt(9 * cin)).astype(np.float32)
+    s1, t1 = r.uniform(0.5, 1.5, c).astype(np.float32), (0.5 * r.standard_normal(c)).astype(np.float32)
+    kd = (r.standard_normal((3, 3, c, 1)) / 3).astype(np.float32)
+    s2, t2 = r.uniform(0.5, 1.5, c).astype(np.float32), (0.5 * r.standard_normal(c)).astype(np.float32)
+    cpad = pack.ceil_to(c, 32)
+    ksf = ks * s1.reshape(1, 1, 1, c)
+    xt = torch.from_numpy(x)
+    if padding == "same":
+        e = O.conv2d(xt, torch.from_numpy(_bf(ksf)), None, stride=2, padding="same")
+        pt, _ = O.same_pad_amounts(H, 3, 2)
+        pl, _ = O.same_pad_amounts(W, 3, 2)
+    else:
+        e = O.conv2d(O.zero_pad2d(xt, padding), torch.from_numpy(_bf(ksf)), None, stride=2)
+        pt = pl = padding
+    SH, SW = e.shape[1], e.shape[2]
+    e = torch.from_numpy(_bf(O.activation(e + torch.from_numpy(t1), act).numpy()))
+    kf = torch.from_numpy(kd * s2.reshape(1, 1, -1, 1))
+    y = O.activation(O.depthwise_conv2d(e, kf, None, 1, "same") + torch.from_numpy(t2), act)
+    wd, b2 = pack.pack_depthwise(kd, s2, t2)
+
+    def padc(a):
+        out = np.zeros(a.shape[:-1] + (cpad,), np.float32)
+        out[..., :c] = a
+        return out
+    hp, wp = max(H + pt, (SH - 1) * 2 + 3), max(W + pl, (SW - 1) * 2 + 3)
+    img = Hh.cast_input_pad(Hh.dev_bf16(x), (pt, hp - H - pt, pl, wp - W - pl))
+    got, sums = Hh.expand_dwconv(img, Hh.dev_bits(pack.pack_stem_frag(ksf, cpad)), Hh.dev_f32(padc(t1)), Hh.dev_f32(padc(wd)),
+                                 Hh.dev_f32(padc(b2)), c, 3, 1, 1, 1, SH, SW, act=act, want_sums=True, stem_hw=(SH, SW))
+    Hh.sync()
+    return max(_err(_cpu(got), y.numpy()), _err(_cpu(sums), _cpu(got).sum((1, 2))) / 10), TOL_BF16
+
+
+CASES["stem_dw_rgb_64_to_32_swish"] = lambda: _stem_dw_case(2, 64, 64, 3, 32, "swish", 360)
+CASES["stem_dw_rgb_odd_75x53_c48"] = lambda: _stem_dw_case(2, 75, 53, 3, 48, "swish", 361)              # odd sizes, 1.5 chunks, ragged tiles
+CASES["stem_dw_rgb_symmetric_pad_relu6"] = lambda: _stem_dw_case(3, 48, 80, 3, 32, "relu6", 362, padding=1)   # MobileNet-V2 style
+CASES["stem_dw_gray_1ch"] = lambda: _stem_dw_case(1, 40, 40, 1, 40, "swish", 363)
+
+
 def _expand_dw_case(B, H, W, cin, c, k, stride, padding, act, seed, squeeze=True):
     """tfimm_hip_expand_dwconv against 1x1 conv + act (rounded to bf16, as the two-launch path stores it) + depthwise + act"""
     import hip_ops as Hh

@@ -229,7 +229,7 @@ def dwconv(x, w, bias, k, stride, pad_t, pad_l, OH, OW, act="", want_sums=False)
     return out, sums
 
 
-def expand_dwconv(x, w1frag, b1, wdw, b2, Cexp, k, stride, pad_t, pad_l, OH, OW, act="", want_sums=False):
+def expand_dwconv(x, w1frag, b1, wdw, b2, Cexp, k, stride, pad_t, pad_l, OH, OW, act="", want_sums=False, stem_hw=None):
     B, H, W, Cin = x.shape
     out = torch.empty(B, OH, OW, Cexp, dtype=torch.bfloat16, device=DEV)
     sums = torch.zeros(B, Cexp, dtype=torch.float32, device=DEV) if want_sums else None
@@ -238,6 +238,9 @@ def expand_dwconv(x, w1frag, b1, wdw, b2, Cexp, k, stride, pad_t, pad_l, OH, OW,
     d.B, d.H, d.W, d.Cin, d.C, d.Cpad = B, H, W, Cin, Cexp, b1.numel()
     d.k, d.stride, d.pad_t, d.pad_l, d.OH, d.OW = k, stride, pad_t, pad_l, OH, OW
     d.act1 = d.act2 = ffi.ACT[act]
+    if stem_hw is not None:        # x is the zero-bordered 4-channel image; stem_hw = the stem convolution's output size
+        d.stem, d.img_h, d.img_w = 1, H, W
+        d.H, d.W = stem_hw
     ffi.check(lib.tfimm_hip_expand_dwconv(C.byref(d), stream()), "expand_dwconv")
     return out, sums
 

@@ -7,10 +7,10 @@ import tfimm
 from tfimm.utils.init import synthetic_weights
 
 
-def _kinds(name, size=None, **kw):
+def _kinds(name, size=None, want_features=False, **kw):
     m = tfimm.create_model(name, **kw)
     m.set_weights(synthetic_weights(m))
-    prog = m.program(*(size or m.cfg.input_size))
+    prog = m.program(*(size or m.cfg.input_size), **({"want_features": True} if want_features else {}))
     return [op.kind for op in prog.ops], prog
 
 
@@ -189,7 +189,13 @@ def test_narrow_mbconv_fronts_are_one_launch(monkeypatch):
     tfimm_hip_expand_dwconv (the expanded tensor never reaches HBM); FLOP count and the following squeeze-excite are unchanged;
     TFIMM_NO_MBCONV_FUSION=1 keeps the GEMM + depthwise pair"""
     kinds, prog = _kinds("efficientnet_b0")
-    fused = [op for op in prog.ops if op.kind == "expand_dwconv"]
+    stem = [op for op in prog.ops if op.kind == "expand_dwconv" and op.attrs.get("stem")]
+    fused = [op for op in prog.ops if op.kind == "expand_dwconv" and not op.attrs.get("stem")]
+    # conv_stem + bn1 + act + the first block's depthwise layer: the 3x3 / stride 2 convolution reads the zero-bordered image
+    # (224 -> 225 rows: TF "same" pads one row / column at the bottom / right), its 112 x 112 x 32 output stays in LDS
+    assert len(stem) == 1 and kinds[:2] == ["cast_input", "expand_dwconv"]
+    a = stem[0].attrs
+    assert (a["Cin"], a["C"], a["H"], a["W"], a["img_h"], a["img_w"], a["k"], a["stride"]) == (4, 32, 112, 112, 225, 225, 3, 1)
     assert [(op.attrs["Cin"], op.attrs["C"], op.attrs["k"], op.attrs["stride"], op.attrs["H"]) for op in fused] == \
         [(16, 96, 3, 2, 112), (24, 144, 3, 1, 56), (24, 144, 5, 2, 56)]
     assert all(op.attrs["sums"] is not None and op.attrs["Cpad"] % 32 == 0 for op in fused)
@@ -199,7 +205,10 @@ def test_narrow_mbconv_fronts_are_one_launch(monkeypatch):
     flops = prog.flops_per_image()
     monkeypatch.setenv("TFIMM_NO_MBCONV_FUSION", "1")
     kinds2, prog2 = _kinds("efficientnet_b0")
-    assert "expand_dwconv" not in kinds2 and len(kinds2) == len(kinds) + 3 and prog2.flops_per_image() == flops
+    assert "expand_dwconv" not in kinds2 and len(kinds2) == len(kinds) + 4 and prog2.flops_per_image() == flops
+    monkeypatch.delenv("TFIMM_NO_MBCONV_FUSION")
+    kinds3, _ = _kinds("efficientnet_b0", want_features=True)          # the "stem" feature needs the stem output in HBM
+    assert kinds3[:3] == ["cast_input", "gemm", "dwconv"]
 
 
 def test_layernorms_with_one_dense_reader_are_folded(monkeypatch):
