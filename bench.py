@@ -409,6 +409,11 @@ def main():
     launched = "WORLD_SIZE" in os.environ
     if not launched and (args.gpus > 1 or args.spawn):
         sys.exit(spawn_ranks(args.gpus))
+    # ONE JSON line on stdout, nothing else: RCCL prints a version banner to fd 1 when its first communicator comes up (and
+    # other libraries may follow), so fd 1 points at stderr while the work runs and the line goes to the saved descriptor
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -457,7 +462,8 @@ def main():
                          for k, v in [(args.workload, m)] + list(also.items())},
             "also": also,
         }
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(saved_stdout, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
