@@ -310,24 +310,28 @@ TFIMM_API int tfimm_hip_bcast_rows(const void* src, void* dst, int B, int n_rows
 /* ---------------------------------------------------------------------------------------
  * tfimm_hip_dwconv: depthwise k x k conv, stride s, explicit (pad_t, pad_l) zero padding,
  * NHWC bf16, folded-BN scale already in w, + bias, + activation.  w: fp32 [k*k][C].
- * Optionally accumulates per-(image, channel) sums of the OUTPUT into sum_out (fp32 [B][C],
- * must be zeroed by the caller) -- the SE squeeze fused into the producer.
+ * Optionally accumulates per-(image, channel) sums of the OUTPUT into sum_out -- the SE squeeze fused into the
+ * producer: int64 [B][C] FIXED-POINT accumulators in units of 2^-20 (zeroed by the caller; read them with
+ * tfimm_hip_se_gate(sums_fixed = 1)).  Integer adds commute, so the sums -- and everything computed from them -- are
+ * bit-identical from launch to launch whatever order the workgroups arrive in (float atomics were not).
  * Replaces DepthwiseConv2D + BatchNormalization + Activation
  * (efficientnet_blocks.py:350-352,443-445; convnext.py:191-197 with act none).
  * ------------------------------------------------------------------------------------- */
-TFIMM_API int tfimm_hip_dwconv(const void* x, const float* w, const float* bias, void* y, float* sum_out,
+TFIMM_API int tfimm_hip_dwconv(const void* x, const float* w, const float* bias, void* y, void* sum_out,
                      int B, int H, int W, int C, int k, int stride, int pad_t, int pad_l,
                      int OH, int OW, int act, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * tfimm_hip_se_gate: gate[b][c] = gate_act( W2 . act( W1 . mean[b] + b1 ) + b2 )[c]
- * with mean[b][c] = sums[b][c] * inv_count.  w1: fp32 [rd][C] (reduce conv, transposed), w2: fp32 [rd][C]
+ * with mean[b][c] = sums[b][c] * inv_count.  sums: fp32 [B][C] (sums_fixed = 0: e.g. the means of tfimm_hip_mean_rows
+ * with inv_count = 1) or the int64 fixed-point accumulators of tfimm_hip_dwconv / tfimm_hip_expand_dwconv (sums_fixed = 1).
+ * w1: fp32 [rd][C] (reduce conv, transposed), w2: fp32 [rd][C]
  * (expand conv as Keras stores it) -- both are walked along C by consecutive threads.
  * SqueezeExcite.call (efficientnet_blocks.py:241-248) / SEModule.call (layers/attention.py:66-74)
  * minus the final multiply, which is fused into the consumer (a_scale of tfimm_hip_gemm)
  * or done by tfimm_hip_scale_channels.
  * ------------------------------------------------------------------------------------- */
-TFIMM_API int tfimm_hip_se_gate(const float* sums, float inv_count, const float* w1, const float* b1,
+TFIMM_API int tfimm_hip_se_gate(const void* sums, int sums_fixed, float inv_count, const float* w1, const float* b1,
                       const float* w2, const float* b2, float* gate, int B, int C, int rd,
                       int act, int gate_act, void* stream);
 
@@ -383,7 +387,7 @@ TFIMM_API int tfimm_hip_conv_chain(const tfimm_chain_desc* d, void* stream);
  *   w1   expand weights (BN scale folded) as MFMA fragments: bf16 [Cpad/32][2][64][8], element
  *        [cc][ks][lane][j] = W1[k = 16 ks + 8 (lane >> 5) + j][c = 32 cc + (lane & 31)], zero for k >= Cin, c >= C
  *   b1, b2  fp32 [Cpad] folded BN shifts;  wdw  fp32 [k*k][Cpad] depthwise taps (BN scale folded), zero padded
- *   y    bf16 [B][OH][OW][C];  sum_out  fp32 [B][C] (zeroed by the caller) or NULL
+ *   y    bf16 [B][OH][OW][C];  sum_out  int64 [B][C] fixed-point squeeze sums as in tfimm_hip_dwconv (zeroed by the caller) or NULL
  * k in {3, 5}, stride in {1, 2}, explicit top / left zero padding of the EXPANDED tensor (bottom / right follow from
  * OH, OW).  Anything else returns TFIMM_EUNSUP and the caller runs the two launches.
  * ------------------------------------------------------------------------------------- */
@@ -394,7 +398,7 @@ typedef struct tfimm_expand_dw_desc {
   const float* wdw;
   const float* b2;
   void* y;
-  float* sum_out;
+  void* sum_out;
   int32_t B, H, W, Cin, C, Cpad, k, stride, pad_t, pad_l, OH, OW;
   int32_t act1, act2;
   int32_t stem;           /* 1: the "expansion" is the network's 3 x 3 / stride 2 RGB stem convolution (conv_stem + bn1 + act,

@@ -60,6 +60,18 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
   return u;
 }
 
+// ---- squeeze sums (SE): per-(image, channel) sums of a layer's output, accumulated by many workgroups.  Float atomics add in
+// whatever order the workgroups arrive, so the last bits -- and through bf16 roundings further down, the logits -- changed from
+// launch to launch.  The accumulators are therefore 64-bit FIXED POINT (2^-20 units: +-8.8e12 of range): every thread
+// converts the partial sum it formed in a fixed order once, and integer adds commute -- results are bit-reproducible.
+typedef long long tfimm_sq_t;
+#define TFIMM_SQ_SCALE 1048576.0f
+__device__ __forceinline__ tfimm_sq_t sq_from_float(float v) { return __float2ll_rn(v * TFIMM_SQ_SCALE); }
+__device__ __forceinline__ void sq_add(tfimm_sq_t* p, tfimm_sq_t q) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)q);
+}
+__device__ __forceinline__ float sq_to_float(tfimm_sq_t q) { return (float)((double)q * (1.0 / 1048576.0)); }
+
 // ---- activations (reference tfimm/layers/factory.py:6-13) -----------------------------
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {

@@ -31,7 +31,7 @@ struct MbArgs {
   const float* wdw;
   const float* b2;
   bf16_t* y;
-  float* sums;
+  tfimm_sq_t* sums;
   int H, W, Cin, C, Cpad, pad_t, pad_l, OH, OW, tiles_x, act1, act2;
   int img_h, img_w;   // STEM: the padded 4-channel image x points at; H, W are then the convolution's output (= depthwise input) size
   int dbg;      // TFIMM_MB_DBG ablation bits: 1 no output stores, 2 no phase-2 activation, 4 no phase-1 activation
@@ -52,7 +52,7 @@ struct MbGeom {
   static constexpr int X_BYTES = STEM ? (XIH * XIW * 8 + 15) / 16 * 16 : NPX * XP, E_BYTES = NPX * EP;
   static constexpr int KS = STEM ? 3 : 2;                      // MFMA k-steps of the expansion (K padded to 48 / 32)
   static constexpr int WD_FLOATS = (K * K + 1) * 32;
-  static constexpr int LDS = X_BYTES + E_BYTES + WD_FLOATS * 4 + 64 * 4;
+  static constexpr int LDS = X_BYTES + E_BYTES + WD_FLOATS * 4 + 64 * 8;
   static_assert(LDS <= 80 * 1024, "two workgroups per CU");
 };
 
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
   unsigned char* Xs = mb_smem;
   unsigned char* Es = mb_smem + G::X_BYTES;
   float* Wd = reinterpret_cast<float*>(Es + G::E_BYTES);
-  float* lsum = Wd + G::WD_FLOATS;
+  tfimm_sq_t* lsum = reinterpret_cast<tfimm_sq_t*>(Wd + G::WD_FLOATS);      // 2 x 32 fixed-point squeeze sums
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int b = blockIdx.y;
   const int ty = blockIdx.x / p.tiles_x, tx = blockIdx.x - ty * p.tiles_x;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
         v = *reinterpret_cast<const uint2*>(xb + ((size_t)gy * p.img_w + gx) * 4);
       *reinterpret_cast<uint2*>(Xs + i * 8) = v;
     }
-    if (tid < 64) lsum[tid] = 0.f;
+    if (tid < 64) lsum[tid] = 0;
   } else {
     const int nch = p.Cin >> 3;
     const bf16_t* xb = p.x + (size_t)b * p.H * p.W * p.Cin;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
         *reinterpret_cast<uint4*>(Xs + px * G::XP + ((c ^ ((px >> 2) & 3)) << 4)) = v;
       }
     }
-    if (tid < 64) lsum[tid] = 0.f;
+    if (tid < 64) lsum[tid] = 0;
   }
   // which of this lane's halo pixels (one per block it expands) lie inside the image
   uint32_t vbits = 0;
@@ -125,8 +125,8 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
     // squeeze sums of the previous chunk: one global atomic per channel, then re-arm that half of the buffer
     if (p.sums && cc > 0 && tid < 32) {
       const int h = ((cc - 1) & 1) * 32 + tid, ch = (cc - 1) * 32 + tid;
-      if (ch < p.C) atomicAdd(p.sums + (size_t)b * p.C + ch, lsum[h]);
-      lsum[h] = 0.f;
+      if (ch < p.C) sq_add(p.sums + (size_t)b * p.C + ch, lsum[h]);
+      lsum[h] = 0;
     }
     // ---- phase 1: expand + activation into LDS ------------------------------------------------------------------------
     bf16x8 af[G::KS];
@@ -261,8 +261,8 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
         }
       }
       if (p.sums) {
-        atomicAdd(&lsum[(cc & 1) * 32 + cp * 2], tot[0]);
-        atomicAdd(&lsum[(cc & 1) * 32 + cp * 2 + 1], tot[1]);
+        sq_add(&lsum[(cc & 1) * 32 + cp * 2], sq_from_float(tot[0]));
+        sq_add(&lsum[(cc & 1) * 32 + cp * 2 + 1], sq_from_float(tot[1]));
       }
     }
     __syncthreads();
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
   if (p.sums && tid < 32) {
     const int cl = nchunks - 1;
     const int ch = cl * 32 + tid;
-    if (ch < p.C) atomicAdd(p.sums + (size_t)b * p.C + ch, lsum[(cl & 1) * 32 + tid]);
+    if (ch < p.C) sq_add(p.sums + (size_t)b * p.C + ch, lsum[(cl & 1) * 32 + tid]);
   }
 }
 
@@ -322,7 +322,7 @@ extern "C" int tfimm_hip_expand_dwconv(const tfimm_expand_dw_desc* d, void* stre
     TFIMM_FAIL(TFIMM_EINVAL, "expand_dwconv: output %dx%d does not fit input %dx%d", d->OH, d->OW, d->H, d->W);
   MbArgs a;
   a.x = (const bf16_t*)d->x; a.w1 = (const uint4*)d->w1; a.b1 = d->b1; a.wdw = d->wdw; a.b2 = d->b2;
-  a.y = (bf16_t*)d->y; a.sums = d->sum_out;
+  a.y = (bf16_t*)d->y; a.sums = reinterpret_cast<tfimm_sq_t*>(d->sum_out);
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.C = d->C; a.Cpad = d->Cpad; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
   a.OH = d->OH; a.OW = d->OW; a.tiles_x = 0; a.act1 = d->act1; a.act2 = d->act2;
   a.img_h = d->img_h; a.img_w = d->img_w;

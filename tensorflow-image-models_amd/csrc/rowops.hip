@@ -535,7 +535,7 @@ __global__ void bcast_rows_kernel(const bf16_t* src, bf16_t* dst, int B, int n_r
 // ---------------------------------------------------------------------------------------
 template <bool VEC>
 __global__ void __launch_bounds__(256) dwconv_kernel(const bf16_t* x, const float* w, const float* bias, bf16_t* y,
-                                                     float* sum_out, int B, int H, int W, int C, int k, int stride,
+                                                     tfimm_sq_t* sum_out, int B, int H, int W, int C, int k, int stride,
                                                      int pad_t, int pad_l, int OH, int OW, int act) {
   constexpr int G = VEC ? 8 : 1;
   const int cg = VEC ? (C >> 3) : C;
@@ -581,12 +581,12 @@ __global__ void __launch_bounds__(256) dwconv_kernel(const bf16_t* x, const floa
         float r[8];
         unpack8(u, r);  // squeeze sees the stored (bf16-rounded) activations
 #pragma unroll
-        for (int e = 0; e < 8; ++e) atomicAdd(sum_out + (int64_t)b * C + c0 + e, r[e]);
+        for (int e = 0; e < 8; ++e) sq_add(sum_out + (int64_t)b * C + c0 + e, sq_from_float(r[e]));
       }
     } else {
       const uint32_t h = f2bf(acc[0]);
       yp[0] = (bf16_t)h;
-      if (sum_out) atomicAdd(sum_out + (int64_t)b * C + c0, bf2f(h));
+      if (sum_out) sq_add(sum_out + (int64_t)b * C + c0, sq_from_float(bf2f(h)));
     }
   }
 }
@@ -620,10 +620,10 @@ __device__ __forceinline__ void dw_unpack(const typename dwvec<CV>::type& u, flo
 template <int K, int S, int PX, int CV>
 __global__ void __launch_bounds__(256) dwconv_strip_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, bf16_t* __restrict__ y,
-                                                           float* sum_out, int H, int W, int C, int pad_t, int pad_l,
+                                                           tfimm_sq_t* sum_out, int H, int W, int C, int pad_t, int pad_l,
                                                            int OH, int OW, int act) {
   typedef typename dwvec<CV>::type vec_t;
-  extern __shared__ float lsum[];  // [CV][cgs]
+  extern __shared__ tfimm_sq_t lsum[];  // [CV][cgs]
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   const int cgs = C / CV;
@@ -631,7 +631,7 @@ __global__ void __launch_bounds__(256) dwconv_strip_kernel(const bf16_t* __restr
   const int items = OH * sx * cgs;
   const ActParams actp = make_act(act);
   if (sum_out) {
-    for (int i = tid; i < CV * cgs; i += 256) lsum[i] = 0.f;
+    for (int i = tid; i < CV * cgs; i += 256) lsum[i] = 0;
     __syncthreads();
   }
   constexpr int COLS = (PX - 1) * S + K;
@@ -718,12 +718,12 @@ __global__ void __launch_bounds__(256) dwconv_strip_kernel(const bf16_t* __restr
     }
     if (sum_out) {
 #pragma unroll
-      for (int e = 0; e < CV; ++e) atomicAdd(&lsum[e * cgs + cg], tot[e]);
+      for (int e = 0; e < CV; ++e) sq_add(&lsum[e * cgs + cg], sq_from_float(tot[e]));
     }
   }
   if (sum_out) {
     __syncthreads();
-    for (int c = tid; c < C; c += 256) atomicAdd(sum_out + (size_t)b * C + c, lsum[(c % CV) * cgs + (c / CV)]);
+    for (int c = tid; c < C; c += 256) sq_add(sum_out + (size_t)b * C + c, lsum[(c % CV) * cgs + (c / CV)]);
   }
 }
 
@@ -757,12 +757,12 @@ static int dw_rows_pairs_per_block(int cps, int sx) {
 template <int K, int S, int PX, int DEPTH, int ACT>
 __global__ void __launch_bounds__(256) dwconv_rows_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, bf16_t* __restrict__ y,
-                                                      float* sum_out, int H, int W, int C, int pad_t, int pad_l, int OH, int OW, int act,
+                                                      tfimm_sq_t* sum_out, int H, int W, int C, int pad_t, int pad_l, int OH, int OW, int act,
                                                       int rows_per_seg, int nseg, int CPB) {
   constexpr int COLS = (PX - 1) * S + K;
   constexpr int NSLOT = (K + S - 1) / S;          // output rows with contributions pending
   constexpr int PERIOD = S * NSLOT;              // input rows per full rotation of the slots
-  extern __shared__ tfimm_f32x2 dw7_lds[];       // [K*K][CPB] filter taps of this workgroup's channel pairs, then [2 CPB] squeeze sums
+  extern __shared__ tfimm_f32x2 dw7_lds[];       // [K*K][CPB] filter taps of this workgroup's channel pairs, then [2 CPB] squeeze sums (64-bit fixed point)
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   const int cps = C / 2;                          // channel pairs
@@ -785,8 +785,8 @@ __global__ void __launch_bounds__(256) dwconv_rows_kernel(const bf16_t* __restri
     const int ch = (ct * CPB + c) * 2;
     dw7_lds[i] = ch < C ? tfimm_f32x2{w[(size_t)tap * C + ch], w[(size_t)tap * C + ch + 1]} : tfimm_f32x2{0.f, 0.f};
   }
-  float* lsum = reinterpret_cast<float*>(dw7_lds + K * K * CPB);
-  if (sum_out && tid < 2 * CPB) lsum[tid] = 0.f;
+  tfimm_sq_t* lsum = reinterpret_cast<tfimm_sq_t*>(dw7_lds + K * K * CPB);
+  if (sum_out && tid < 2 * CPB) lsum[tid] = 0;
   __syncthreads();
   tfimm_f32x2 tot = {0.f, 0.f};
   if (live) {
@@ -883,16 +883,16 @@ __global__ void __launch_bounds__(256) dwconv_rows_kernel(const bf16_t* __restri
   }
   if (sum_out) {
     if (live) {
-      atomicAdd(&lsum[2 * cpl], tot.x);
-      atomicAdd(&lsum[2 * cpl + 1], tot.y);
+      sq_add(&lsum[2 * cpl], sq_from_float(tot.x));
+      sq_add(&lsum[2 * cpl + 1], sq_from_float(tot.y));
     }
     __syncthreads();
-    if (tid < 2 * CPB && ct * CPB * 2 + tid < C) atomicAdd(sum_out + (size_t)b * C + ct * CPB * 2 + tid, lsum[tid]);
+    if (tid < 2 * CPB && ct * CPB * 2 + tid < C) sq_add(sum_out + (size_t)b * C + ct * CPB * 2 + tid, lsum[tid]);
   }
 }
 
 template <int K, int S>
-static int launch_dwconv_rows(const bf16_t* x, const float* w, const float* bias, bf16_t* y, float* sum_out, int B, int H,
+static int launch_dwconv_rows(const bf16_t* x, const float* w, const float* bias, bf16_t* y, tfimm_sq_t* sum_out, int B, int H,
                               int W, int C, int pad_t, int pad_l, int OH, int OW, int act, hipStream_t st) {
   constexpr int PX = 4;
   const int cps = C / 2;
@@ -907,7 +907,7 @@ static int launch_dwconv_rows(const bf16_t* x, const float* w, const float* bias
   nseg = (OH + rows_per_seg - 1) / rows_per_seg;
   const int64_t gx = (int64_t)ctiles * sgroups * nseg;
   if (gx > 0x7fffffffLL) TFIMM_FAIL(TFIMM_EINVAL, "dwconv: grid too large");
-  const size_t lds = (size_t)(K * K + 1) * CPB * sizeof(tfimm_f32x2);
+  const size_t lds = (size_t)(K * K + 2) * CPB * sizeof(tfimm_f32x2);      // taps + 2 CPB fixed-point squeeze sums
   // input rows in flight per thread: 2 measured slower than 1 (EfficientNet-B4 depthwise 4.68 -> 5.36 ms: the second buffer
   // costs a wave per SIMD), TFIMM_DW_DEPTH=2 keeps it selectable for the swish flavour
   static const int depth = getenv("TFIMM_DW_DEPTH") ? atoi(getenv("TFIMM_DW_DEPTH")) : 1;
@@ -928,7 +928,7 @@ static int launch_dwconv_rows(const bf16_t* x, const float* w, const float* bias
 
 
 template <int K, int S>
-static int launch_dwconv_strip(const bf16_t* x, const float* w, const float* bias, bf16_t* y, float* sum_out, int B,
+static int launch_dwconv_strip(const bf16_t* x, const float* w, const float* bias, bf16_t* y, tfimm_sq_t* sum_out, int B,
                                int H, int W, int C, int pad_t, int pad_l, int OH, int OW, int act, hipStream_t st) {
   constexpr int PX = 4;
   // 4 channels per thread keep the accumulators + one filter row of weights under 64 VGPRs for the
@@ -939,7 +939,7 @@ static int launch_dwconv_strip(const bf16_t* x, const float* w, const float* bia
   int64_t bpi = (items + 255) / 256;                    // blocks per image if every thread took one item
   const int64_t want = (8 * 256 + B - 1) / B;           // ~8 resident blocks per CU over the whole grid
   if (bpi > want) bpi = want < 1 ? 1 : want;
-  const size_t lds = sum_out ? (size_t)C * sizeof(float) : 0;
+  const size_t lds = sum_out ? (size_t)C * sizeof(tfimm_sq_t) : 0;
   TFIMM_LAUNCH((dwconv_strip_kernel<K, S, PX, CV>), dim3((unsigned)bpi, (unsigned)B), dim3(256), lds, st, x, w, bias, y,
                sum_out, H, W, C, pad_t, pad_l, OH, OW, act);
   return 0;
@@ -953,7 +953,7 @@ static int launch_dwconv_strip(const bf16_t* x, const float* w, const float* bia
 // ([rd][C]: the Keras layout of the expand conv) by consecutive threads -- all loads coalesced.  (256 threads and a
 // [C][rd] w2 walked row-per-thread took 67 us for C = 1632.)
 constexpr int SE_IMG = 1;
-__global__ void __launch_bounds__(1024) se_gate_kernel(const float* __restrict__ sums, float inv_count,
+__global__ void __launch_bounds__(1024) se_gate_kernel(const void* __restrict__ sums_v, int sums_fixed, float inv_count,
                                                       const float* __restrict__ w1, const float* __restrict__ b1,
                                                       const float* __restrict__ w2, const float* __restrict__ b2,
                                                       float* __restrict__ gate, int B, int C, int rd, int act,
@@ -964,7 +964,11 @@ __global__ void __launch_bounds__(1024) se_gate_kernel(const float* __restrict__
   const int b0 = blockIdx.x * SE_IMG;
   for (int i = threadIdx.x; i < SE_IMG * C; i += blockDim.x) {
     const int im = i / C;
-    mean[i] = b0 + im < B ? sums[(int64_t)b0 * C + i] * inv_count : 0.f;
+    float sv = 0.f;
+    if (b0 + im < B)
+      sv = sums_fixed ? sq_to_float(reinterpret_cast<const tfimm_sq_t*>(sums_v)[(int64_t)b0 * C + i])
+                      : reinterpret_cast<const float*>(sums_v)[(int64_t)b0 * C + i];
+    mean[i] = sv * inv_count;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -1352,9 +1356,10 @@ extern "C" int tfimm_hip_bcast_rows(const void* src, void* dst, int B, int n_row
   return 0;
 }
 
-extern "C" int tfimm_hip_dwconv(const void* x, const float* w, const float* bias, void* y, float* sum_out, int B,
+extern "C" int tfimm_hip_dwconv(const void* x, const float* w, const float* bias, void* y, void* sum_out_v, int B,
                                 int H, int W, int C, int k, int stride, int pad_t, int pad_l, int OH, int OW,
                                 int act, void* stream) {
+  tfimm_sq_t* sum_out = reinterpret_cast<tfimm_sq_t*>(sum_out_v);
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || stride <= 0 || OH <= 0 || OW <= 0)
     TFIMM_FAIL(TFIMM_EINVAL, "dwconv: bad arguments");
   hipStream_t st = (hipStream_t)stream;
@@ -1392,7 +1397,7 @@ extern "C" int tfimm_hip_dwconv(const void* x, const float* w, const float* bias
   return 0;
 }
 
-extern "C" int tfimm_hip_se_gate(const float* sums, float inv_count, const float* w1, const float* b1,
+extern "C" int tfimm_hip_se_gate(const void* sums, int sums_fixed, float inv_count, const float* w1, const float* b1,
                                  const float* w2, const float* b2, float* gate, int B, int C, int rd, int act,
                                  int gate_act, void* stream) {
   if (!sums || !w1 || !w2 || !gate || B <= 0 || C <= 0 || rd <= 0) TFIMM_FAIL(TFIMM_EINVAL, "se_gate: bad arguments");
@@ -1403,7 +1408,7 @@ extern "C" int tfimm_hip_se_gate(const float* sums, float inv_count, const float
     TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)se_gate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  TFIMM_LAUNCH(se_gate_kernel, dim3((B + SE_IMG - 1) / SE_IMG), dim3(1024), lds, (hipStream_t)stream, sums, inv_count, w1, b1, w2, b2,
+  TFIMM_LAUNCH(se_gate_kernel, dim3((B + SE_IMG - 1) / SE_IMG), dim3(1024), lds, (hipStream_t)stream, sums, sums_fixed, inv_count, w1, b1, w2, b2,
                gate, B, C, rd, act, gate_act);
   return 0;
 }

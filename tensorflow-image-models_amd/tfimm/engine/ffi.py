@@ -117,7 +117,7 @@ SYMBOLS = {
     "tfimm_hip_mean_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "tfimm_hip_bcast_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "tfimm_hip_dwconv": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "tfimm_hip_se_gate": (_i, [_vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "tfimm_hip_se_gate": (_i, [_vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tfimm_hip_scale_channels": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tfimm_hip_patch_merge_ln": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "tfimm_hip_attention_probs": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),

@@ -677,7 +677,7 @@ class Builder:
         sums = None
         ins = [x]
         if squeeze:
-            sums = p.new_tensor(1, c, dtype="f32", name=(name or kernel) + ":sums")
+            sums = p.new_tensor(1, 2 * c, dtype="f32", name=(name or kernel) + ":sums")     # int64 fixed point per channel
         p.add("dwconv", ins, out, consts, cite=cite, extra_outputs=[sums] if sums is not None else [],
               H=x.H, W=x.W, C=c, k=kh, stride=stride, pad_t=pt, pad_l=pl, OH=OH, OW=OW, act=act,
               sums=None if sums is None else sums.id)
@@ -718,7 +718,7 @@ class Builder:
         consts = {"w1": p.new_const(w1, pw_kernel + ":frag"), "b1": p.new_const(padc(np.asarray(t1, np.float32)), pw_kernel + ":bias"),
                   "wdw": p.new_const(padc(wd), dw_kernel + ":pad"), "b2": p.new_const(padc(b2), dw_kernel + ":bias")}
         out = p.new_tensor(OH * OW, c, OH, OW, name=dw_kernel)
-        sums = p.new_tensor(1, c, dtype="f32", name=dw_kernel + ":sums") if squeeze else None
+        sums = p.new_tensor(1, 2 * c, dtype="f32", name=dw_kernel + ":sums") if squeeze else None     # int64 fixed point
         p.add("expand_dwconv", [x], out, consts, cite=cite, extra_outputs=[sums] if sums is not None else [],
               H=x.H, W=x.W, Cin=cin, C=c, Cpad=cpad, k=kh, stride=stride, pad_t=pt, pad_l=pl, OH=OH, OW=OW, act=act,
               sums=None if sums is None else sums.id,
@@ -768,7 +768,7 @@ class Builder:
         consts = {"w1": p.new_const(w1, stem_kernel + ":frag"), "b1": p.new_const(padc(np.asarray(t1, np.float32)), stem_kernel + ":bias"),
                   "wdw": p.new_const(padc(wd), dw_kernel + ":pad"), "b2": p.new_const(padc(b2), dw_kernel + ":bias")}
         out = p.new_tensor(OH * OW, c, OH, OW, name=dw_kernel)
-        sums = p.new_tensor(1, c, dtype="f32", name=dw_kernel + ":sums") if squeeze else None
+        sums = p.new_tensor(1, 2 * c, dtype="f32", name=dw_kernel + ":sums") if squeeze else None     # int64 fixed point
         p.add("expand_dwconv", [x], out, consts, cite=cite, extra_outputs=[sums] if sums is not None else [],
               H=SH, W=SW, Cin=4, C=c, Cpad=cpad, k=3, stride=1, pad_t=dpt, pad_l=dpl, OH=OH, OW=OW, act=act,
               sums=None if sums is None else sums.id, stem=1, img_h=hp, img_w=wp,
@@ -788,8 +788,11 @@ class Builder:
             "b2": p.new_const(self.wget(b_expand), b_expand),
         }
         gate = p.new_tensor(1, c, dtype="f32", name="se_gate")
+        # sums straight from a depthwise producer are int64 fixed point (2 floats of storage per channel); means are fp32
+        fixed = sums.C == 2 * c
+        assert fixed or sums.C == c
         p.add("se_gate", [sums], gate, consts, cite=cite, C=c, rd=rd, inv_count=1.0 / count, act=act,
-              gate_act=gate_act)
+              gate_act=gate_act, sums_fixed=1 if fixed else 0)
         return gate
 
     def scale_channels(self, x: TRef, gate: TRef, residual: Optional[TRef] = None, relu_after=False, cite="") -> TRef:
@@ -994,7 +997,7 @@ class Plan:
                 d.sum_out = None
                 if a["sums"] is not None:
                     d.sum_out = self.tptr(a["sums"])
-                    self.calls.append(("memset", (d.sum_out, B * a["C"] * 4)))
+                    self.calls.append(("memset", (d.sum_out, B * a["C"] * 8)))
                 d.B, d.H, d.W, d.Cin, d.C, d.Cpad = B, a["H"], a["W"], a["Cin"], a["C"], a["Cpad"]
                 d.k, d.stride, d.pad_t, d.pad_l, d.OH, d.OW = a["k"], a["stride"], a["pad_t"], a["pad_l"], a["OH"], a["OW"]
                 d.act1 = d.act2 = ffi.ACT[a["act"]]
@@ -1074,14 +1077,14 @@ class Plan:
                 sums_ptr = None
                 if a["sums"] is not None:
                     sums_ptr = self.tptr(a["sums"])
-                    self.calls.append(("memset", (sums_ptr, B * a["C"] * 4)))
+                    self.calls.append(("memset", (sums_ptr, B * a["C"] * 8)))
                 self.calls.append((lib.tfimm_hip_dwconv,
                                    (self.tptr(op.inputs[0]), self.cptr(op.consts["w"]), self.cptr(op.consts.get("bias")),
                                     self.tptr(op.output), sums_ptr, B, a["H"], a["W"], a["C"], a["k"], a["stride"],
                                     a["pad_t"], a["pad_l"], a["OH"], a["OW"], ffi.ACT[a["act"]])))
             elif k == "se_gate":
                 self.calls.append((lib.tfimm_hip_se_gate,
-                                   (self.tptr(op.inputs[0]), a["inv_count"], self.cptr(op.consts["w1"]),
+                                   (self.tptr(op.inputs[0]), a["sums_fixed"], a["inv_count"], self.cptr(op.consts["w1"]),
                                     self.cptr(op.consts["b1"]), self.cptr(op.consts["w2"]), self.cptr(op.consts["b2"]),
                                     self.tptr(op.output), B, a["C"], a["rd"], ffi.ACT[a["act"]], ffi.ACT[a["gate_act"]])))
             elif k == "scale_channels":

@@ -685,7 +685,7 @@ def _dw_case(B, H, W, Cc, k, stride, padding, act, seed):
                           want_sums=True)
     Hh.sync()
     e = _err(_cpu(got), y.numpy())
-    es = _err(_cpu(sums), _cpu(got).sum((1, 2)))   # sums are of the stored bf16 outputs
+    es = _err(Hh.sums_to_float(sums), _cpu(got).astype(np.float64).sum((1, 2)))   # sums are of the stored bf16 outputs
     return max(e, es / 10), TOL_BF16
 
 
@@ -828,7 +828,7 @@ def _stem_dw_case(B, H, W, cin, c, act, seed, padding="same"):
     got, sums = Hh.expand_dwconv(img, Hh.dev_bits(pack.pack_stem_frag(ksf, cpad)), Hh.dev_f32(padc(t1)), Hh.dev_f32(padc(wd)),
                                  Hh.dev_f32(padc(b2)), c, 3, 1, 1, 1, SH, SW, act=act, want_sums=True, stem_hw=(SH, SW))
     Hh.sync()
-    return max(_err(_cpu(got), y.numpy()), _err(_cpu(sums), _cpu(got).sum((1, 2))) / 10), TOL_BF16
+    return max(_err(_cpu(got), y.numpy()), _err(Hh.sums_to_float(sums), _cpu(got).astype(np.float64).sum((1, 2))) / 10), TOL_BF16
 
 
 CASES["stem_dw_rgb_64_to_32_swish"] = lambda: _stem_dw_case(2, 64, 64, 3, 32, "swish", 360)
@@ -874,7 +874,7 @@ def _expand_dw_case(B, H, W, cin, c, k, stride, padding, act, seed, squeeze=True
     Hh.sync()
     err = _err(_cpu(got), y.numpy())
     if squeeze:
-        err = max(err, _err(_cpu(sums), _cpu(got).sum((1, 2))) / 10)      # sums are of the stored bf16 outputs
+        err = max(err, _err(Hh.sums_to_float(sums), _cpu(got).astype(np.float64).sum((1, 2))) / 10)      # sums are of the stored bf16 outputs
     return err, TOL_BF16
 
 
@@ -900,6 +900,10 @@ def _se_case(B, R, Cc, rd, seed):
     hid = O.activation(mean @ torch.from_numpy(w1.T) + torch.from_numpy(b1), "swish")
     gate = torch.sigmoid(hid @ torch.from_numpy(w2.T) + torch.from_numpy(b2)).numpy()
     g = H.se_gate(H.dev_f32(sums), 1.0 / R, H.dev_f32(w1), H.dev_f32(b1), H.dev_f32(np.ascontiguousarray(w2.T)), H.dev_f32(b2), "swish")
+    # the same sums as 64-bit fixed point (what the depthwise kernels accumulate): identical gate up to the 2^-20 quantum
+    q = torch.from_numpy(np.rint(sums.astype(np.float64) * 2.0 ** 20).astype(np.int64)).to(H.DEV)
+    gq = H.se_gate(q, 1.0 / R, H.dev_f32(w1), H.dev_f32(b1), H.dev_f32(np.ascontiguousarray(w2.T)), H.dev_f32(b2), "swish")
+    assert float((gq - g).abs().max()) < 1e-5
     res = _bf(r.standard_normal((B, R, Cc)))
     y = H.scale_channels(H.dev_bf16(x), g, H.dev_bf16(res), relu_after=True)
     H.sync()

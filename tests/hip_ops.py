@@ -223,7 +223,7 @@ def bcast_rows(src, dst, B, n_rows, d, dst_rows):
 def dwconv(x, w, bias, k, stride, pad_t, pad_l, OH, OW, act="", want_sums=False):
     B, H, W, Cc = x.shape
     out = torch.empty(B, OH, OW, Cc, dtype=torch.bfloat16, device=DEV)
-    sums = torch.zeros(B, Cc, dtype=torch.float32, device=DEV) if want_sums else None
+    sums = torch.zeros(B, Cc, dtype=torch.int64, device=DEV) if want_sums else None      # fixed point, 2^-20 units
     ffi.check(lib.tfimm_hip_dwconv(ptr(x), ptr(w), ptr(bias), ptr(out), ptr(sums), B, H, W, Cc, k, stride, pad_t,
                                    pad_l, OH, OW, ffi.ACT[act], stream()), "dwconv")
     return out, sums
@@ -232,7 +232,7 @@ def dwconv(x, w, bias, k, stride, pad_t, pad_l, OH, OW, act="", want_sums=False)
 def expand_dwconv(x, w1frag, b1, wdw, b2, Cexp, k, stride, pad_t, pad_l, OH, OW, act="", want_sums=False, stem_hw=None):
     B, H, W, Cin = x.shape
     out = torch.empty(B, OH, OW, Cexp, dtype=torch.bfloat16, device=DEV)
-    sums = torch.zeros(B, Cexp, dtype=torch.float32, device=DEV) if want_sums else None
+    sums = torch.zeros(B, Cexp, dtype=torch.int64, device=DEV) if want_sums else None    # fixed point, 2^-20 units
     d = ffi.ExpandDwDesc()
     d.x, d.w1, d.b1, d.wdw, d.b2, d.y, d.sum_out = ptr(x), ptr(w1frag), ptr(b1), ptr(wdw), ptr(b2), ptr(out), ptr(sums)
     d.B, d.H, d.W, d.Cin, d.C, d.Cpad = B, H, W, Cin, Cexp, b1.numel()
@@ -245,11 +245,16 @@ def expand_dwconv(x, w1frag, b1, wdw, b2, Cexp, k, stride, pad_t, pad_l, OH, OW,
     return out, sums
 
 
+def sums_to_float(sums):
+    """int64 fixed-point squeeze sums (2^-20 units) -> float64 numpy"""
+    return sums.cpu().numpy().astype(np.float64) / 2.0 ** 20
+
+
 def se_gate(sums, inv_count, w1, b1, w2, b2, act, gate_act="sigmoid"):
     B, Cc = sums.shape
     rd = w1.shape[0]
     gate = torch.empty(B, Cc, dtype=torch.float32, device=DEV)
-    ffi.check(lib.tfimm_hip_se_gate(ptr(sums), float(inv_count), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(gate), B, Cc,
+    ffi.check(lib.tfimm_hip_se_gate(ptr(sums), 1 if sums.dtype == torch.int64 else 0, float(inv_count), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(gate), B, Cc,
                                     rd, ffi.ACT[act], ffi.ACT[gate_act], stream()), "se_gate")
     return gate
 

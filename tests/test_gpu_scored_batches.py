@@ -2,12 +2,13 @@
 
 At B = 256 / 512 the persistent GEMM workgroups walk many tiles, the XCD ranges differ from a B = 2 launch, other tile
 shapes are picked and > 2 GiB tensors are chunked -- none of which the B = 1..2 model tests exercise.  For each scored
-configuration: (i) rows of the big-batch logits equal the B = 2 forward of the same images (bit for bit where every
-reduction has a fixed order; EfficientNet's SE squeeze accumulates per-channel sums with fp32 atomics whose order
-changes from launch to launch -- 1e-7-level gate differences flip bf16 roundings further down, so that model gets a band
-of 2e-2 of the largest logit, a few bf16 ulps, and its run-to-run spread at the same batch must sit inside the same
-band), and
-(ii) a 16-image subset meets the usual bar against the fp32 oracle."""
+configuration: (i) two launches at the scored batch size give bit-identical logits -- every reduction has a fixed order,
+and EfficientNet's SE squeeze, which many workgroups accumulate concurrently, sums in 64-bit fixed point (integer adds
+commute; with fp32 atomics the logits moved by up to 1e-2 of their range from launch to launch); (ii) rows of the
+big-batch logits equal the B = 2 forward of the same images, bit for bit for ResNet-50 / ViT-B / Swin-B; EfficientNet-B4
+gets a band of 1e-2 of the largest logit there, because its depthwise kernels split an image into more row segments at small
+batches and a thread's fp32 partial squeeze sum then rounds differently before it is converted; and
+(iii) a 16-image subset meets the usual bar against the fp32 oracle."""
 import numpy as np
 import pytest
 import torch
@@ -19,7 +20,7 @@ from tfimm.utils.init import synthetic_weights
 
 pytestmark = pytest.mark.gpu
 
-ATOMIC_BAND = 2e-2        # max over 256 x 1000 logits; observed 0.5e-2 .. 1.1e-2 between two runs of the same plan
+BATCH_BAND = 1e-2         # EfficientNet-B4, batch 2 vs batch 256 (max over the logits of the compared rows)
 SCORED = [("resnet50", 256, True), ("vit_base_patch16_224", 512, True), ("swin_base_patch4_window7_224", 256, True),
           ("efficientnet_b4", 256, False)]
 
@@ -37,17 +38,14 @@ def test_scored_batch(name, batch, exact):
     x = ((x - mean) / std).to(torch.bfloat16).contiguous()
     big = model(x).numpy()
     big_replay = model(x).numpy()                       # second call: hipGraph replay of the same plan
-    if exact:
-        assert np.array_equal(big, big_replay)
-    else:
-        assert mc.rel_err(big_replay, big) <= ATOMIC_BAND
+    assert np.array_equal(big, big_replay), (name, float(np.abs(big - big_replay).max()))
     picks = [0, 1, batch // 2 - 1, batch // 2, batch - 2, batch - 1]
     for lo in (0, batch // 2 - 1, batch - 2):           # first, middle (an XCD range boundary) and last pair
         small = model(x[lo:lo + 2]).numpy()
         if exact:
             assert np.array_equal(small, big[lo:lo + 2]), (name, lo, float(np.abs(small - big[lo:lo + 2]).max()))
         else:
-            assert mc.rel_err(small, big[lo:lo + 2]) <= ATOMIC_BAND, (name, lo)
+            assert mc.rel_err(small, big[lo:lo + 2]) <= BATCH_BAND, (name, lo)
     # 16 images spread over the batch against the fp32 oracle
     idx = np.unique(np.linspace(0, batch - 1, 16).astype(int))
     xs = x[torch.from_numpy(idx).cuda()].float().cpu().numpy()
