@@ -103,6 +103,7 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
     }
     if (tid < 64) lsum[tid] = 0;
   }
+  __syncthreads();          // the halo is read by other threads than the ones that staged it
   // which of this lane's halo pixels (one per block it expands) lie inside the image
   uint32_t vbits = 0;
 #pragma unroll

@@ -793,6 +793,45 @@ CASES["ln_gemm_one_k_tile"] = lambda: _ln_gemm_case(5000, 32, 96, "", 349, offse
 CASES["ln_gemm_multi_round"] = lambda: _ln_gemm_case(70000, 128, 256, "", 348, offset=1.0)
 
 
+def _expand_dw_many_images_case(B, H, W, cin, c, k, stride, seed):
+    """many workgroups per CU at once (the batch sizes that are benchmarked): the fused launch must equal the two-launch path
+    (tfimm_hip_gemm + tfimm_hip_dwconv) to a bf16 ulp and itself bit for bit -- a missing barrier behind the halo staging
+    passed every small-batch case and broke at 64+ images"""
+    import hip_ops as Hh
+    r = _rng(seed)
+    x = _bf(r.standard_normal((B, H, W, cin)))
+    k1 = (r.standard_normal((cin, c)) / np.sqrt(cin)).astype(np.float32)
+    t1 = (0.5 * r.standard_normal(c)).astype(np.float32)
+    kd = (r.standard_normal((k, k, c, 1)) / k).astype(np.float32)
+    t2 = (0.5 * r.standard_normal(c)).astype(np.float32)
+    cpad = pack.ceil_to(c, 32)
+    wd, b2 = pack.pack_depthwise(kd, None, t2)
+
+    def padc(a):
+        out = np.zeros(a.shape[:-1] + (cpad,), np.float32)
+        out[..., :c] = a
+        return out
+    OH, OW = -(-H // stride), -(-W // stride)
+    pt, _ = O.same_pad_amounts(H, k, stride)
+    pl, _ = O.same_pad_amounts(W, k, stride)
+    xd = Hh.dev_bf16(x)
+    wt, bvec = pack.pack_dense(k1, t1)
+    e = Hh.gemm(xd.reshape(-1, cin), Hh.dev_bits(wt), c, cin, bias=Hh.dev_f32(bvec), act="swish")
+    ref, ref_s = Hh.dwconv(e.reshape(B, H, W, c), Hh.dev_f32(wd), Hh.dev_f32(b2), k, stride, pt, pl, OH, OW, act="swish", want_sums=True)
+    args = (xd, Hh.dev_bits(pack.pack_expand_frag(k1, cpad)), Hh.dev_f32(padc(t1)), Hh.dev_f32(padc(wd)), Hh.dev_f32(padc(b2)),
+            c, k, stride, pt, pl, OH, OW)
+    got, sums = Hh.expand_dwconv(*args, act="swish", want_sums=True)
+    got2, sums2 = Hh.expand_dwconv(*args, act="swish", want_sums=True)
+    Hh.sync()
+    assert torch.equal(got, got2) and torch.equal(sums, sums2), "two launches of the fused kernel differ"
+    return max(_err(_cpu(got), _cpu(ref)), _err(Hh.sums_to_float(sums), Hh.sums_to_float(ref_s))), TOL_BF16
+
+
+CASES["expand_dw_b96_k3s2_vs_two_launch"] = lambda: _expand_dw_many_images_case(96, 94, 94, 24, 144, 3, 2, 370)
+CASES["expand_dw_b96_k3s1_vs_two_launch"] = lambda: _expand_dw_many_images_case(96, 47, 47, 32, 192, 3, 1, 371)
+CASES["expand_dw_b96_k5s2_vs_two_launch"] = lambda: _expand_dw_many_images_case(96, 47, 47, 32, 192, 5, 2, 372)
+
+
 def _stem_dw_case(B, H, W, cin, c, act, seed, padding="same"):
     """stem flavour of tfimm_hip_expand_dwconv: 3x3 / stride 2 convolution of the RGB image + act (rounded to bf16) followed by
     a 3x3 depthwise layer + act, against the same two layers in fp32"""
