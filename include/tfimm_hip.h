@@ -427,10 +427,11 @@ TFIMM_API int tfimm_hip_attention_probs(const void* qkv, void* probs, int B, int
  * mean / population variance over (H, W, C/groups), y = x*inv + (beta - mean*inv), inv = rsqrt(var+eps)*gamma
  * (tf.nn.batch_normalization), then act, then (+ residual, act_after_res) when residual != NULL -- the
  * norm + activation + shortcut add of a ResNet block whose norm_layer is "group_norm" (resnet.py:269-290).
- * x / residual / y: bf16 [B][rows][C]; gamma / beta: fp32 [C]; stats_ws: fp32 [B][groups][2] scratch (zeroed here).
+ * x / residual / y: bf16 [B][rows][C]; gamma / beta: fp32 [C]; stats_ws: int64 [B][groups][2] scratch (zeroed here): sum and
+ * sum of squares in 2^-20 fixed point, so the statistics do not depend on the order the workgroups add them in.
  * ------------------------------------------------------------------------------------- */
 TFIMM_API int tfimm_hip_group_norm(const void* x, const float* gamma, const float* beta, const void* residual, void* y,
-                         float* stats_ws, int B, int rows, int C, int groups, float eps, int act,
+                         void* stats_ws, int B, int rows, int C, int groups, float eps, int act,
                          int act_after_res, void* stream);
 
 /* ---------------------------------------------------------------------------------------

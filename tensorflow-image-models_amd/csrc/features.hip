@@ -77,13 +77,15 @@ extern "C" int tfimm_hip_attention_probs(const void* qkv, void* probs, int B, in
 // channel vector (V = 8 or 1 channels) in registers across its rows, the per-channel totals meet in LDS, the G group
 // totals leave with one global atomic pair per group and workgroup.
 template <int V>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ stats, int rows,
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, tfimm_sq_t* __restrict__ stats, int rows,
                                                        int C, int G, int rows_per_block) {
-  extern __shared__ __attribute__((aligned(16))) float gn_lds[];      // [C][2]
+  // totals in 64-bit fixed point (common.h, squeeze sums): integer adds commute, so the statistics -- and the network's
+  // output -- do not depend on the order in which threads and workgroups arrive
+  extern __shared__ __attribute__((aligned(16))) tfimm_sq_t gn_lds[];      // [C][2]
   const int b = blockIdx.y;
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(rows, r0 + rows_per_block);
-  for (int c = threadIdx.x; c < 2 * C; c += 256) gn_lds[c] = 0.f;
+  for (int c = threadIdx.x; c < 2 * C; c += 256) gn_lds[c] = 0;
   __syncthreads();
   const int nvec = C / V;
   const int nvp = min(nvec, 256);                 // vectors covered per pass of the workgroup
@@ -110,27 +112,27 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
       }
 #pragma unroll
       for (int e = 0; e < V; ++e) {
-        atomicAdd(&gn_lds[2 * (v * V + e)], s[e]);
-        atomicAdd(&gn_lds[2 * (v * V + e) + 1], q[e]);
+        sq_add(&gn_lds[2 * (v * V + e)], sq_from_float(s[e]));
+        sq_add(&gn_lds[2 * (v * V + e) + 1], sq_from_float(q[e]));
       }
     }
   }
   __syncthreads();
   const int S = C / G;
   for (int g = threadIdx.x; g < G; g += 256) {
-    float s = 0.f, q = 0.f;
+    tfimm_sq_t s = 0, q = 0;
     for (int c = g * S; c < (g + 1) * S; ++c) {
       s += gn_lds[2 * c];
       q += gn_lds[2 * c + 1];
     }
-    atomicAdd(&stats[((int64_t)b * G + g) * 2], s);
-    atomicAdd(&stats[((int64_t)b * G + g) * 2 + 1], q);
+    sq_add(&stats[((int64_t)b * G + g) * 2], s);
+    sq_add(&stats[((int64_t)b * G + g) * 2 + 1], q);
   }
 }
 
 // Pass 2: y = act_after(act((x - mean) * rsqrt(var + eps) * gamma + beta) + residual)
 template <int V>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ stats,
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, const tfimm_sq_t* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const bf16_t* __restrict__ residual, bf16_t* __restrict__ y,
                                                        int rows, int C, int G, float eps, int act, int act_after,
@@ -140,9 +142,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
   const int S = C / G;
   const float inv_n = 1.f / ((float)rows * (float)S);
   for (int g = threadIdx.x; g < G; g += 256) {
-    const float s = stats[((int64_t)b * G + g) * 2], q = stats[((int64_t)b * G + g) * 2 + 1];
-    const float mean = s * inv_n;
-    const float var = fmaxf(q * inv_n - mean * mean, 0.f);
+    const double s = (double)stats[((int64_t)b * G + g) * 2] * (1.0 / 1048576.0);
+    const double q = (double)stats[((int64_t)b * G + g) * 2 + 1] * (1.0 / 1048576.0);
+    const float mean = (float)(s * inv_n);
+    const float var = fmaxf((float)(q * inv_n - (s * inv_n) * (s * inv_n)), 0.f);
     gn_ms[2 * g] = mean;
     gn_ms[2 * g + 1] = rsqrtf(var + eps);
   }
@@ -182,14 +185,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
 }
 
 extern "C" int tfimm_hip_group_norm(const void* x, const float* gamma, const float* beta, const void* residual, void* y,
-                                    float* stats_ws, int B, int rows, int C, int groups, float eps, int act,
+                                    void* stats_ws_v, int B, int rows, int C, int groups, float eps, int act,
                                     int act_after_res, void* stream) {
+  tfimm_sq_t* stats_ws = reinterpret_cast<tfimm_sq_t*>(stats_ws_v);
   if (!x || !gamma || !beta || !y || !stats_ws) TFIMM_FAIL(TFIMM_EINVAL, "group_norm: null pointer");
   if (B <= 0 || rows <= 0 || C <= 0 || groups <= 0 || C % groups) TFIMM_FAIL(TFIMM_EINVAL, "group_norm: bad shape");
   if (B > 65535) TFIMM_FAIL(TFIMM_EUNSUP, "group_norm: batch %d > 65535", B);
-  if ((size_t)C * 8 > 64 * 1024) TFIMM_FAIL(TFIMM_EUNSUP, "group_norm: %d channels", C);
+  if ((size_t)C * 16 > 64 * 1024) TFIMM_FAIL(TFIMM_EUNSUP, "group_norm: %d channels", C);
   hipStream_t st = (hipStream_t)stream;
-  TFIMM_HIP_CHECK(hipMemsetAsync(stats_ws, 0, (size_t)B * groups * 2 * sizeof(float), st));
+  TFIMM_HIP_CHECK(hipMemsetAsync(stats_ws, 0, (size_t)B * groups * 2 * sizeof(tfimm_sq_t), st));
   // enough workgroups to fill the chip, at least 8 rows each
   int per = (int)cdiv64((int64_t)rows * B, 2048);
   if (per < 8) per = 8;
@@ -198,11 +202,11 @@ extern "C" int tfimm_hip_group_norm(const void* x, const float* gamma, const flo
   const bool vec = (C & 7) == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;
   const dim3 grid((unsigned)chunks, (unsigned)B);
   if (vec) {
-    TFIMM_LAUNCH(gn_stats_kernel<8>, grid, dim3(256), (size_t)C * 8, st, (const bf16_t*)x, stats_ws, rows, C, groups, per);
+    TFIMM_LAUNCH(gn_stats_kernel<8>, grid, dim3(256), (size_t)C * 16, st, (const bf16_t*)x, stats_ws, rows, C, groups, per);
     TFIMM_LAUNCH(gn_apply_kernel<8>, grid, dim3(256), (size_t)groups * 8, st, (const bf16_t*)x, stats_ws, gamma, beta,
                  (const bf16_t*)residual, (bf16_t*)y, rows, C, groups, eps, act, act_after_res, per);
   } else {
-    TFIMM_LAUNCH(gn_stats_kernel<1>, grid, dim3(256), (size_t)C * 8, st, (const bf16_t*)x, stats_ws, rows, C, groups, per);
+    TFIMM_LAUNCH(gn_stats_kernel<1>, grid, dim3(256), (size_t)C * 16, st, (const bf16_t*)x, stats_ws, rows, C, groups, per);
     TFIMM_LAUNCH(gn_apply_kernel<1>, grid, dim3(256), (size_t)groups * 8, st, (const bf16_t*)x, stats_ws, gamma, beta,
                  (const bf16_t*)residual, (bf16_t*)y, rows, C, groups, eps, act, act_after_res, per);
   }

@@ -809,7 +809,7 @@ class Builder:
         g, b = self.wget(prefix + "/gamma"), self.wget(prefix + "/beta")
         assert g.shape[0] == x.C and x.C % groups == 0, f"{prefix}: {x.C} channels, {groups} groups"
         out = p.new_tensor(x.rows, x.C, x.H, x.W, name=prefix)
-        ws = p.new_tensor(1, 2 * groups, dtype="f32", name=prefix + ":stats")
+        ws = p.new_tensor(1, 4 * groups, dtype="f32", name=prefix + ":stats")       # int64 [groups][2] fixed-point sums
         consts = {"gamma": p.new_const(g, prefix + "/gamma"), "beta": p.new_const(b, prefix + "/beta")}
         ins = [x] + ([residual] if residual is not None else [])
         if residual is not None:

@@ -284,7 +284,7 @@ def attention_probs(qkv, B, n, heads, hd, scale):
 def group_norm(x, gamma, beta, groups, eps, act="", residual=None, act_after=""):
     B, R, Cc = x.shape
     out = torch.empty_like(x)
-    ws = torch.full((B, groups, 2), 7.0, dtype=torch.float32, device=DEV)     # poisoned: the entry point zeroes it
+    ws = torch.full((B, groups, 2), 7, dtype=torch.int64, device=DEV)         # poisoned: the entry point zeroes it
     ffi.check(lib.tfimm_hip_group_norm(ptr(x), ptr(gamma), ptr(beta), ptr(residual), ptr(out), ptr(ws), B, R, Cc, groups,
                                        float(eps), ffi.ACT[act], ffi.ACT[act_after], stream()), "group_norm")
     return out
