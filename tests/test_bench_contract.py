@@ -60,7 +60,8 @@ def test_one_rank_through_the_launcher():
                         "--warmup", "1", "--workload", "vit_tiny_patch16_224", "--batch", "8", "--no-cpu-baseline",
                         "--extra", ""], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout[:2000]      # the JSON line and nothing else (RCCL's banner goes to stderr)
+    line = json.loads(r.stdout)
     assert line["n_gpus"] == 1 and line["config"]["launcher"] == "bench.py spawn"
     assert line["config"]["exchange"].startswith("RCCL") and line["config"]["launch"] == "hipGraph replay"
     assert line["value"] > 0 and len(line["per_rank_ms"]) == 1 and line["roofline"]["frac"] > 0
