@@ -21,6 +21,7 @@
 //   CU so one's global loads / stores sit under the other's arithmetic.  HBM traffic: input halo once + output once.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -115,12 +116,6 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
   }
   const ActParams a1 = make_act(ACT >= 0 ? ACT : p.act1), a2 = make_act(ACT >= 0 ? ACT : p.act2);
   const int nchunks = p.Cpad >> 5;
-  // phase-2 role of this thread
-  const int cp = tid & 15, slot = tid >> 4, col = slot % OTW, rg = slot / OTW;
-  const uint32_t* ep = reinterpret_cast<const uint32_t*>(Es + ((rg * G::RPT * S) * G::IW + col * S) * G::EP + cp * 4);
-  const tfimm_f32x2* wl = reinterpret_cast<const tfimm_f32x2*>(Wd) + cp;
-  const int ox = ox0 + col;
-  const int oyb = oy0 + rg * G::RPT;
 
   for (int cc = 0; cc < nchunks; ++cc) {
     // squeeze sums of the previous chunk: one global atomic per channel, then re-arm that half of the buffer
@@ -213,25 +208,37 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
     }
     __syncthreads();
     // ---- phase 2: depthwise taps out of LDS ------------------------------------------------------------------------------
-    {
+    // A last chunk of at most 16 channels (48 = 32 + 16, 144 = 4 x 32 + 16) would leave half of the 16 channel-pair columns
+    // idle: it runs with 8 channel pairs x 64 pixel slots instead, every thread marching half as many rows.
+    auto phase2 = [&](auto hc) __attribute__((always_inline)) {
+      constexpr bool HALF = decltype(hc)::value;
+      constexpr int NCPL = HALF ? 8 : 16;                       // channel pairs handled side by side
+      constexpr int RGL = (G::NT / NCPL) / OTW;                 // row groups
+      constexpr int RPTL = OTH / RGL;                           // output rows per thread
+      constexpr int NRL = (RPTL - 1) * S + K;
+      const int cpl = tid % NCPL, slotl = tid / NCPL;
+      const int coll = slotl % OTW, rgl = slotl / OTW;
+      const uint32_t* epl = reinterpret_cast<const uint32_t*>(Es + ((rgl * RPTL * S) * G::IW + coll * S) * G::EP + cpl * 4);
+      const tfimm_f32x2* wll = reinterpret_cast<const tfimm_f32x2*>(Wd) + cpl;
+      const int oxl = ox0 + coll, oybl = oy0 + rgl * RPTL;
       tfimm_f32x2 w[K * K];
 #pragma unroll
-      for (int t = 0; t < K * K; ++t) w[t] = wl[t * 16];
-      const tfimm_f32x2 bias2 = wl[K * K * 16];
-      tfimm_f32x2 acc[G::RPT];
+      for (int t = 0; t < K * K; ++t) w[t] = wll[t * 16];
+      const tfimm_f32x2 bias2 = wll[K * K * 16];
+      tfimm_f32x2 acc[RPTL];
 #pragma unroll
-      for (int r = 0; r < G::RPT; ++r) acc[r] = bias2;
+      for (int r = 0; r < RPTL; ++r) acc[r] = bias2;
 #pragma unroll
-      for (int j = 0; j < G::NR; ++j) {
+      for (int j = 0; j < NRL; ++j) {
         tfimm_f32x2 v[K];
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
-          const uint32_t raw = ep[(j * G::IW + kx) * (G::EP / 4)];
+          const uint32_t raw = epl[(j * G::IW + kx) * (G::EP / 4)];
           v[kx] = tfimm_f32x2{__uint_as_float(raw << 16), __uint_as_float(raw & 0xffff0000u)};
         }
 #pragma unroll
         for (int ky = 0; ky < K; ++ky) {
-          if (j - ky >= 0 && (j - ky) % S == 0 && (j - ky) / S < G::RPT) {
+          if (j - ky >= 0 && (j - ky) % S == 0 && (j - ky) / S < RPTL) {
 #pragma unroll
             for (int kx = 0; kx < K; ++kx)
               acc[(j - ky) / S] = __builtin_elementwise_fma(v[kx], w[ky * K + kx], acc[(j - ky) / S]);
@@ -239,21 +246,21 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
         }
         if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keeps hipcc from hoisting every row's LDS reads to the top
       }
-      const int c0 = cc * 32 + cp * 2;
-      const bool cok = c0 < p.C && ox < p.OW;
+      const int c0 = cc * 32 + cpl * 2;
+      const bool cok = c0 < p.C && oxl < p.OW;
       tfimm_f32x2 tot = {0.f, 0.f};
-      bf16_t* yb = p.y + (((size_t)b * p.OH + oyb) * p.OW + ox) * p.C + c0;
+      bf16_t* yb = p.y + (((size_t)b * p.OH + oybl) * p.OW + oxl) * p.C + c0;
 #pragma unroll
-      for (int r0 = 0; r0 < G::RPT; r0 += 4) {
+      for (int r0 = 0; r0 < RPTL; r0 += 4) {
         tfimm_f32x2 v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (r0 + e < G::RPT) ? acc[(r0 + e < G::RPT) ? r0 + e : 0] : tfimm_f32x2{0.f, 0.f};
+        for (int e = 0; e < 4; ++e) v[e] = (r0 + e < RPTL) ? acc[(r0 + e < RPTL) ? r0 + e : 0] : tfimm_f32x2{0.f, 0.f};
         if (!(p.dbg & 2)) act8p(v, a2);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if (r0 + e < G::RPT) {
+          if (r0 + e < RPTL) {
             const uint32_t pk = pack_bf2(v[e][0], v[e][1]);
-            if (cok && oyb + r0 + e < p.OH) {
+            if (cok && oybl + r0 + e < p.OH) {
               if (!(p.dbg & 1)) *reinterpret_cast<uint32_t*>(yb + (size_t)(r0 + e) * p.OW * p.C) = pk;
               // the squeeze sees the stored (bf16-rounded) activations, as in tfimm_hip_dwconv
               tot += tfimm_f32x2{__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)};
@@ -262,10 +269,13 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
         }
       }
       if (p.sums) {
-        sq_add(&lsum[(cc & 1) * 32 + cp * 2], sq_from_float(tot[0]));
-        sq_add(&lsum[(cc & 1) * 32 + cp * 2 + 1], sq_from_float(tot[1]));
+        sq_add(&lsum[(cc & 1) * 32 + cpl * 2], sq_from_float(tot[0]));
+        sq_add(&lsum[(cc & 1) * 32 + cpl * 2 + 1], sq_from_float(tot[1]));
       }
-    }
+    };
+    constexpr bool HALF_OK = (G::NT / 8) % OTW == 0 && OTH % ((G::NT / 8) / OTW) == 0;
+    if (HALF_OK && p.C - cc * 32 <= 16) phase2(std::integral_constant<bool, HALF_OK>{});
+    else phase2(std::false_type{});
     __syncthreads();
   }
   if (p.sums && tid < 32) {
