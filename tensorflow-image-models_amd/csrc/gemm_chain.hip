@@ -65,12 +65,14 @@ extern "C" int tfimm_hip_conv_chain(const tfimm_chain_desc* dp, void* stream) {
   }
 
   const int vi = d.N2 == 512;
-  const gemm_chain_fn fn = vi ? gemm_chain_kernel<8> : gemm_chain_kernel<4>;
+  const int ri = (d.act1 == TFIMM_ACT_RELU && d.act2 == TFIMM_ACT_RELU) ? 1 : 0;      // the ResNet case: activations compiled in
+  const gemm_chain_fn fn = ri ? (vi ? gemm_chain_kernel<8, TFIMM_ACT_RELU> : gemm_chain_kernel<4, TFIMM_ACT_RELU>)
+                              : (vi ? gemm_chain_kernel<8> : gemm_chain_kernel<4>);
   const int lds = ChainGeom::LDS_BYTES;
-  static bool ready[2] = {};
-  if (!ready[vi]) {
+  static bool ready[2][2] = {};
+  if (!ready[vi][ri]) {
     TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    ready[vi] = true;
+    ready[vi][ri] = true;
   }
   int64_t grid = ((int64_t)chain_num_cu() * 2 + 7) / 8 * 8;      // two 4-wave workgroups per CU (80 KiB of LDS each)
   const int64_t need = ((int64_t)a.n_tiles + 7) / 8 * 8;

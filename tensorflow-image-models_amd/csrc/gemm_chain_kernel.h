@@ -87,7 +87,9 @@ struct ChainIdx {
 
 // NS2 = N2 / 128 GEMM-2 steps per tile.  Every VMEM operation sits in straight-line code (the step bodies are instantiated
 // per step index), so hipcc's own vmcnt bookkeeping for the residual / bias loads stays exact next to the LDS-DMA.
-template <int NS2>
+// ACT >= 0: both activations are that TFIMM_ACT_* (ResNet: relu) with their parameters folded into the instructions -- the
+// kernel sits at the scalar-register limit and run-time activation parameters are another 14 SGPRs; ACT < 0: p.act1 / p.act2
+template <int NS2, int ACT = -1>
 __global__ void __launch_bounds__(256, 2) gemm_chain_kernel(const ChainArgs p) {
   using G = ChainGeom;
   constexpr int BM = G::BM, NW = G::NW, STAGE = G::STAGE, BN2 = G::BN2, NST = G::NST;
@@ -193,7 +195,7 @@ __global__ void __launch_bounds__(256, 2) gemm_chain_kernel(const ChainArgs p) {
   constexpr int STORES = PASSES * ITS;                                         // store instructions per wave and GEMM-2 step (4)
   constexpr int EPI_LOADS = PASSES * ITS + PASSES * 2;                         // residual + bias loads per wave and step (8)
   auto epi_slot = [](int row, int slot) -> int { return WTN == 64 ? (slot ^ (row & 15)) : (slot ^ ((row >> 1) & 7)); };
-  const ActParams act1p = make_act(p.act1), act2p = make_act(p.act2);
+  const ActParams act1p = make_act(ACT >= 0 ? ACT : p.act1), act2p = make_act(ACT >= 0 ? ACT : p.act2);
   const int e_row = lane / LPR, e_c8 = lane % LPR;
   const bool has_res = p.residual != nullptr;
   float* const sEw = sEpi + wave * (G::EPI_WAVE / 4);
