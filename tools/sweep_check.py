@@ -1,0 +1,32 @@
+"""Compare the logits tools/sweep_forward.py saved on the GPU box with the fp32 oracle (CPU; run where gpurun_out/ is)."""
+import os, sys, glob, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tensorflow-image-models_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+os.environ.setdefault("TFIMM_ALLOW_NO_GPU", "1")
+import numpy as np
+import tfimm, oracle
+from tfimm.utils.init import synthetic_weights
+import model_checks as mc
+
+d = os.path.join(ROOT, "gpurun_out", "sweep")
+rows = []
+for f in sorted(glob.glob(os.path.join(d, "*.npy"))):
+    name = os.path.basename(f)[:-4]
+    if len(sys.argv) > 1 and sys.argv[1] not in name:
+        continue
+    t0 = time.time()
+    m = tfimm.create_model(name)
+    w = synthetic_weights(m, 2021)
+    x = mc.make_input(m.cfg, 2, 2021)
+    ref = oracle.forward(m.cfg, w, x)
+    got = np.load(f).reshape(ref.shape)
+    err = mc.rel_err(got, ref)
+    agree = float((got.argmax(-1) == ref.argmax(-1)).mean())
+    rows.append((err, name, agree))
+    print(f"{name:45s} rel-to-max {err:.3e} top1 {agree:.2f}  ({time.time() - t0:.0f} s)", flush=True)
+errs = sorted(rows, reverse=True)
+print("\nworst:", [(n, f"{e:.2e}") for e, n, _ in errs[:8]])
+print(f"{len(rows)} models, {sum(e <= mc.TOL_LOGITS for e, _, _ in rows)} within {mc.TOL_LOGITS}")
+for f in sorted(glob.glob(os.path.join(d, "*.err"))):
+    print("ERROR", os.path.basename(f), open(f).read().strip()[:200])
