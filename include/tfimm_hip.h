@@ -373,6 +373,14 @@ typedef struct tfimm_chain_desc {
   int32_t C1, N2;
   int32_t ldw1, ldw2, ldr, ldc;
   int32_t act1, act2;       /* TFIMM_ACT_*; act2 is applied after the residual add */
+  const void* ds_x;         /* optional: the shortcut is a 1x1 convolution + BN of the block INPUT (first block of a stage,
+                               resnet.py:315-330): bf16 [M][ds_cin], ds_cin = 64.  Its product accumulates into the second
+                               GEMM's accumulators -- out = act2(mid . W2^T + ds_x . Wds^T + b2), the caller adding the
+                               shortcut's folded-BN shift to b2 -- so neither that launch nor its tensor exists.
+                               residual must be NULL, activations relu. */
+  const void* ds_w;         /* its weights (BN scale folded) as MFMA fragments: bf16 [N2/32][4][64][8], element
+                               [blk][t][lane][e] = Wds[k = 16 t + 8 (lane >> 5) + e][n = 32 blk + (lane & 31)] */
+  int32_t ds_cin;
 } tfimm_chain_desc;
 
 TFIMM_API int tfimm_hip_conv_chain(const tfimm_chain_desc* d, void* stream);

@@ -45,6 +45,12 @@ extern "C" int tfimm_hip_conv_chain(const tfimm_chain_desc* dp, void* stream) {
   const int64_t w1_bytes = (int64_t)d.C1 * d.ldw1 * 2, w2_bytes = (int64_t)d.N2 * d.ldw2 * 2;
   const int64_t out_bytes = ((M - 1) * d.ldc + d.N2) * 2;
   const int64_t res_bytes = d.residual ? ((M - 1) * d.ldr + d.N2) * 2 : 0;
+  const bool ds = d.ds_x != nullptr;
+  if (ds != (d.ds_w != nullptr)) TFIMM_FAIL(TFIMM_EINVAL, "conv_chain: ds_x and ds_w go together");
+  if (ds && (d.residual || d.ds_cin != 64 || (((uintptr_t)d.ds_x | (uintptr_t)d.ds_w) & 15)))
+    TFIMM_FAIL(TFIMM_EUNSUP, "conv_chain: the shortcut convolution is built for a 64-channel block input and no other residual");
+  if (ds && !(d.act1 == TFIMM_ACT_RELU && d.act2 == TFIMM_ACT_RELU))
+    TFIMM_FAIL(TFIMM_EUNSUP, "conv_chain: the shortcut-convolution flavour is built with relu activations");
   if (M > 0x7fffff00LL || x_bytes > 0x7fffff00LL || w1_bytes > 0x7fffff00LL || w2_bytes > 0x7fffff00LL ||
       out_bytes > 0x7fffff00LL || res_bytes > 0x7fffff00LL)
     TFIMM_FAIL(TFIMM_EUNSUP, "conv_chain: a tensor exceeds the 2 GiB a buffer descriptor addresses");
@@ -52,6 +58,7 @@ extern "C" int tfimm_hip_conv_chain(const tfimm_chain_desc* dp, void* stream) {
   ChainArgs a;
   a.x = (const bf16_t*)d.x; a.w1 = (const bf16_t*)d.w1; a.b1 = d.b1;
   a.w2 = (const bf16_t*)d.w2; a.b2 = d.b2; a.residual = (const bf16_t*)d.residual; a.out = (bf16_t*)d.out;
+  a.ds_x = (const bf16_t*)d.ds_x; a.ds_w = (const uint4*)d.ds_w; a.ds_bytes = ds ? (unsigned)(M * 128) : 0u;
   a.M = (int)M; a.N2 = d.N2;
   a.B = d.B; a.H = d.H; a.W = d.W;
   a.ldw1 = d.ldw1; a.ldw2 = d.ldw2; a.ldr = d.ldr; a.ldc = d.ldc;
@@ -66,13 +73,15 @@ extern "C" int tfimm_hip_conv_chain(const tfimm_chain_desc* dp, void* stream) {
 
   const int vi = d.N2 == 512;
   const int ri = (d.act1 == TFIMM_ACT_RELU && d.act2 == TFIMM_ACT_RELU) ? 1 : 0;      // the ResNet case: activations compiled in
-  const gemm_chain_fn fn = ri ? (vi ? gemm_chain_kernel<8, TFIMM_ACT_RELU> : gemm_chain_kernel<4, TFIMM_ACT_RELU>)
-                              : (vi ? gemm_chain_kernel<8> : gemm_chain_kernel<4>);
+  const gemm_chain_fn fn = ds ? (vi ? gemm_chain_kernel<8, TFIMM_ACT_RELU, true> : gemm_chain_kernel<4, TFIMM_ACT_RELU, true>)
+                           : ri ? (vi ? gemm_chain_kernel<8, TFIMM_ACT_RELU> : gemm_chain_kernel<4, TFIMM_ACT_RELU>)
+                                : (vi ? gemm_chain_kernel<8> : gemm_chain_kernel<4>);
   const int lds = ChainGeom::LDS_BYTES;
-  static bool ready[2][2] = {};
-  if (!ready[vi][ri]) {
+  static bool ready[2][3] = {};
+  const int fi = ds ? 2 : ri;
+  if (!ready[vi][fi]) {
     TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    ready[vi][ri] = true;
+    ready[vi][fi] = true;
   }
   int64_t grid = ((int64_t)chain_num_cu() * 2 + 7) / 8 * 8;      // two 4-wave workgroups per CU (80 KiB of LDS each)
   const int64_t need = ((int64_t)a.n_tiles + 7) / 8 * 8;

@@ -45,12 +45,14 @@ struct ChainArgs {
   const bf16_t* w2;         // [N2][ldw2] bf16, K axis in pack.chain_k_order
   const float* b2;          // [N2]
   const bf16_t* residual;   // [M][ldr] or null
+  const bf16_t* ds_x;       // DS flavour: the block input [M][64] whose 1x1 convolution IS the shortcut (resnet.py:315-330)
+  const uint4* ds_w;        // DS flavour: its weights as MFMA fragments [N2 / 32][4][64 lanes][8] (pack.pack_chain_ds)
   bf16_t* out;              // [M][ldc]
   int M, N2;
   int B, H, W;
   int ldw1, ldw2, ldr, ldc;
   int act1, act2;           // act2 is applied after the residual add
-  unsigned x_bytes, w1_bytes, w2_bytes, out_bytes, res_bytes;
+  unsigned x_bytes, w1_bytes, w2_bytes, out_bytes, res_bytes, ds_bytes;
   int n_tiles;              // ceil(M / 128)
   int dbg;                  // TFIMM_CHAIN_DBG ablation switches (0 in production)
 };
@@ -89,7 +91,11 @@ struct ChainIdx {
 // per step index), so hipcc's own vmcnt bookkeeping for the residual / bias loads stays exact next to the LDS-DMA.
 // ACT >= 0: both activations are that TFIMM_ACT_* (ResNet: relu) with their parameters folded into the instructions -- the
 // kernel sits at the scalar-register limit and run-time activation parameters are another 14 SGPRs; ACT < 0: p.act1 / p.act2
-template <int NS2, int ACT = -1>
+// DS: the shortcut of the block is a 1x1 convolution of the 64-channel block input (first block of a stage): instead of reading
+// its 256-channel result as the residual, the four extra k-steps  W_ds . x0  accumulate into the SAME accumulators as GEMM 2
+// (operands straight from global memory into registers: 16 bytes of x0 per lane and k-step once per tile, the weight fragments
+// per slice), so that launch and its tensor disappear; its folded-BN shift is added to b2 on the host.
+template <int NS2, int ACT = -1, bool DS = false>
 __global__ void __launch_bounds__(256, 2) gemm_chain_kernel(const ChainArgs p) {
   using G = ChainGeom;
   constexpr int BM = G::BM, NW = G::NW, STAGE = G::STAGE, BN2 = G::BN2, NST = G::NST;
@@ -127,7 +133,7 @@ __global__ void __launch_bounds__(256, 2) gemm_chain_kernel(const ChainArgs p) {
   const __amdgpu_buffer_rsrc_t rsrc_w1 = make_rsrc(p.w1, p.w1_bytes);
   const __amdgpu_buffer_rsrc_t rsrc_w2 = make_rsrc(p.w2, p.w2_bytes);
   const __amdgpu_buffer_rsrc_t rsrc_o = make_rsrc(p.out, p.out_bytes);
-  const __amdgpu_buffer_rsrc_t rsrc_r = make_rsrc(p.residual, p.res_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_r = DS ? make_rsrc(p.ds_x, p.ds_bytes) : make_rsrc(p.residual, p.res_bytes);
 
   static_assert(NS2 >= 2, "the counted waits below are derived for at least two GEMM-2 steps");
   constexpr int LOOK = NST - 1;
@@ -193,11 +199,13 @@ __global__ void __launch_bounds__(256, 2) gemm_chain_kernel(const ChainArgs p) {
   constexpr int PASSES = BN2 / WTN;                                            // epilogue passes per GEMM-2 step
   constexpr int BPP = WTN / 32;                                                // accumulator blocks per pass
   constexpr int STORES = PASSES * ITS;                                         // store instructions per wave and GEMM-2 step (4)
-  constexpr int EPI_LOADS = PASSES * ITS + PASSES * 2;                         // residual + bias loads per wave and step (8)
+  constexpr int DS_X = DS ? 4 : 0;                                             // x0 fragment loads per wave and tile (behind tap 8)
+  constexpr int DS_W = DS ? 8 : 0;                                             // shortcut weight fragment loads per wave and slice
+  constexpr int EPI_LOADS = (DS ? 0 : PASSES * ITS) + PASSES * 2;              // residual + bias loads per wave and step
   auto epi_slot = [](int row, int slot) -> int { return WTN == 64 ? (slot ^ (row & 15)) : (slot ^ ((row >> 1) & 7)); };
   const ActParams act1p = make_act(ACT >= 0 ? ACT : p.act1), act2p = make_act(ACT >= 0 ? ACT : p.act2);
   const int e_row = lane / LPR, e_c8 = lane % LPR;
-  const bool has_res = p.residual != nullptr;
+  const bool has_res = !DS && p.residual != nullptr;
   float* const sEw = sEpi + wave * (G::EPI_WAVE / 4);
 
   // VMEM operations a step issues, in issue order (taps: their weight DMA; tap 8 first requests slice 0's residual / bias;
@@ -207,9 +215,9 @@ __global__ void __launch_bounds__(256, 2) gemm_chain_kernel(const ChainArgs p) {
   struct Ops {
     static constexpr int all(int r) {           // r = position in the tile program
       if (r < NK1 - 1) return B1_INSTR;
-      if (r == NK1 - 1) return EPI_LOADS + B1_INSTR;
+      if (r == NK1 - 1) return EPI_LOADS + DS_X + B1_INSTR;
       const int u = r - NK1;
-      return (u < NS2 - 1 ? EPI_LOADS : 0) + B2_INSTR + (u == 0 ? STRIP_INSTR : 0) + STORES;
+      return (u < NS2 - 1 ? EPI_LOADS : 0) + DS_W + B2_INSTR + (u == 0 ? STRIP_INSTR : 0) + STORES;
     }
     static constexpr int behind_dma(int r) {    // what step r issues after its weight DMA
       if (r < NK1) return 0;
@@ -279,6 +287,7 @@ __global__ void __launch_bounds__(256, 2) gemm_chain_kernel(const ChainArgs p) {
     // residual rows + bias of GEMM-2 slice u, requested one step before that slice runs (behind tap 8 for slice 0) and
     // ahead of that step's LDS-DMA: two register sets, slice u uses set u & 1
     uint4 rres[2][PASSES][ITS];
+    u32x4 dsx[4];                                      // DS: x0 fragments of this tile
     float4 braw[2][PASSES][2];
     const int e_m = m0 + wave * 32 + e_row;            // output row at iteration 0
     const int em = e_m < p.M ? e_m : p.M;              // clamp: offsets stay inside 32 bits; rows >= M fall off the descriptor
@@ -288,10 +297,12 @@ __global__ void __launch_bounds__(256, 2) gemm_chain_kernel(const ChainArgs p) {
       const unsigned res_off0 = (unsigned)(((size_t)em * p.ldr + u * BN2 + e_c8 * 8) * 2);
 #pragma unroll
       for (int g = 0; g < PASSES; ++g) {
+        if constexpr (!DS) {
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
           const unsigned off = res_off0 + (unsigned)(it * RPI) * ldr2 + (unsigned)(g * WTN * 2);
           rres[u & 1][g][it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, (int)((p.dbg & 4) ? kOobOffset : off), 0, 0));
+        }
         }
         braw[u & 1][g][0] = *reinterpret_cast<const float4*>(p.b2 + u * BN2 + g * WTN + e_c8 * 8);
         braw[u & 1][g][1] = *reinterpret_cast<const float4*>(p.b2 + u * BN2 + g * WTN + e_c8 * 8 + 4);
@@ -304,7 +315,17 @@ __global__ void __launch_bounds__(256, 2) gemm_chain_kernel(const ChainArgs p) {
       else chain_wait_vm<Ops::wait_for(k)>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if constexpr (k == NK1 - 1) { load_epi(ChainIdx<0>{}); __builtin_amdgcn_sched_barrier(0); }
+      if constexpr (k == NK1 - 1) {
+        load_epi(ChainIdx<0>{});
+        if constexpr (DS) {
+          // this lane's pixel (accumulator layout: lane & 31), channels 16 t + 8 fhi .. + 7 of the block input: the B operand
+          // of the shortcut's k-step t.  Rows >= M fall off the descriptor (zeros).
+          const unsigned xo = (unsigned)(m0 + wave * 32 + frow) * 128u + (unsigned)fhi * 16u;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) dsx[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, (int)(xo + t * 32), 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       issue_step(ChainIdx<k + LOOK>{}, tile);
       if constexpr (k == NK1 - 1) __builtin_amdgcn_sched_barrier(0);
       constexpr int ky = k / 3, kx = k % 3;
@@ -367,6 +388,13 @@ __global__ void __launch_bounds__(256, 2) gemm_chain_kernel(const ChainArgs p) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if constexpr (u + 1 < NS2) load_epi(ChainIdx<u + 1>{});
+      u32x4 wds[TN2][4];
+      if constexpr (DS) {
+#pragma unroll
+        for (int j = 0; j < TN2; ++j)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) wds[j][t] = __builtin_bit_cast(u32x4, p.ds_w[(size_t)((u * TN2 + j) * 4 + t) * 64 + lane]);
+      }
       __builtin_amdgcn_sched_barrier(0);      // keep every one of those loads ahead of the LDS-DMA in issue order
       issue_step(ChainIdx<NK1 + u + LOOK>{}, tile);
       if constexpr (u == 0) issue_strip(tile + t_step, tile + t_step < t_hi);   // every wave has passed GEMM 1: the strip is free
@@ -387,6 +415,14 @@ __global__ void __launch_bounds__(256, 2) gemm_chain_kernel(const ChainArgs p) {
 #pragma unroll
           for (int j = 0; j < TN2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], bmid[t], acc[j], 0, 0, 0);
         }
+      }
+      if constexpr (DS) {     // + W_ds . x0: the shortcut convolution, four more k-steps into the same accumulators
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < TN2; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wds[j][t]), __builtin_bit_cast(bf16x8, dsx[t]),
+                                                             acc[j], 0, 0, 0);
       }
       rotate();
 

@@ -16,6 +16,7 @@ normalisation as its own kernel behind each convolution (tfimm_hip_group_norm, w
 fused); BlurPool anti-aliasing is tfimm_hip_blur_pool.
 """
 import math
+import os
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
@@ -255,6 +256,7 @@ class ResNet(Model):
         for idx, bidx, in_ch, nb_ch, out_ch, stride, down in self._stages():
             p = f"layer{idx + 1}/{bidx}"
             shortcut = x
+            ds_spec = None
             if down:
                 if c.downsample_mode == "avg":
                     # resnet.py:295-312 (ResNet-D): AveragePooling2D(2, stride, "same") -> 1x1 conv -> norm.  At even
@@ -274,12 +276,24 @@ class ResNet(Model):
                         shortcut = conv_norm(pooled, kname, p + "/downsample/2", cite="resnet.py:304-312")
                 else:
                     pd = (stride + c.down_kernel_size) // 2 - 1                       # resnet.py:319
-                    shortcut = conv_norm(x, p + "/downsample/0/kernel", p + "/downsample/1", stride=stride, padding=pd,
+
+                    def emit_shortcut(x=x, p=p, stride=stride, pd=pd):
+                        return conv_norm(x, p + "/downsample/0/kernel", p + "/downsample/1", stride=stride, padding=pd,
                                          cite="resnet.py:315-330")
+                    # a 1x1 / stride 1 shortcut convolution of a 64-channel input (first block of stage 1) can be multiplied
+                    # inside the fused bottleneck tail: decided below, emitted here otherwise
+                    if (c.block == "bottleneck" and stride == 1 and c.down_kernel_size == 1 and x.C == 64 and not gn
+                            and os.environ.get("TFIMM_NO_CHAIN_SHORTCUT", "0") != "1"):
+                        shortcut = None
+                        ds_spec = (x, p + "/downsample/0/kernel", p + "/downsample/1", emit_shortcut)
+                    else:
+                        shortcut = emit_shortcut()
             se = c.attn_layer == "se"
             gated = c.attn_layer in ("se", "eca")       # the gate sits between the last norm and the shortcut add
-            last = dict(residual=None if gated else shortcut, act="" if gated else act, act_after=not gated)
             use_aa = bool(c.aa_layer) and stride == 2                                  # resnet.py:127,218
+            if ds_spec is not None and (gated or use_aa or c.cardinality != 1 or act != "relu"):
+                shortcut, ds_spec = ds_spec[3](), None       # the fused tail will not be used: emit the shortcut now
+            last = dict(residual=None if gated else shortcut, act="" if gated else act, act_after=not gated)
             cstride = 1 if use_aa else stride
             if c.block == "basic_block":
                 y = conv_norm(x, p + "/conv1/kernel", p + "/bn1", stride=cstride, padding=1, act=act,
@@ -319,7 +333,11 @@ class ResNet(Model):
                     # conv2 + bn2 + act2 + conv3 + bn3 + shortcut add + act3 as one launch: the `width`-channel
                     # intermediate stays in LDS (stages 1 and 2; None for shapes that kernel is not built for)
                     fused = b.conv_chain(y, k2, p + "/bn2", p + "/conv3/kernel", p + "/bn3", stride=cstride, padding=1,
-                                         bn_eps=eps, act1=act, act2=act, residual=shortcut, cite="resnet.py:273-290")
+                                         bn_eps=eps, act1=act, act2=act, residual=shortcut,
+                                         shortcut_conv=None if ds_spec is None else ds_spec[:3], cite="resnet.py:273-290")
+                if ds_spec is not None and fused is None:       # shape outside the fused kernel: the shortcut as its own launch
+                    shortcut = ds_spec[3]()
+                    last = dict(residual=shortcut, act=act, act_after=True)
                 if fused is not None:
                     y = fused
                 else:

@@ -78,6 +78,7 @@ class ChainDesc(C.Structure):
         ("C1", C.c_int32), ("N2", C.c_int32),
         ("ldw1", C.c_int32), ("ldw2", C.c_int32), ("ldr", C.c_int32), ("ldc", C.c_int32),
         ("act1", C.c_int32), ("act2", C.c_int32),
+        ("ds_x", C.c_void_p), ("ds_w", C.c_void_p), ("ds_cin", C.c_int32),
     ]
 
 

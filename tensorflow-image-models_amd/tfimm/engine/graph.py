@@ -344,7 +344,7 @@ class Builder:
         return out
 
     def conv_chain(self, x: TRef, kernel1: str, bn1: str, kernel2: str, bn2: str, *, stride=1, padding=1, bn_eps=1e-5,
-                   act1="relu", act2="relu", residual: Optional[TRef] = None, cite="") -> Optional[TRef]:
+                   act1="relu", act2="relu", residual: Optional[TRef] = None, shortcut_conv=None, cite="") -> Optional[TRef]:
         """k x k Conv2D + BN + act1 followed by a 1x1 Conv2D + BN (+ residual) + act2 as ONE launch
         (tfimm_hip_conv_chain): the tail of a ResNet bottleneck block with the intermediate kept in LDS.  Returns None
         when the shape is outside what that kernel is built for (the caller then lowers the two convolutions)."""
@@ -356,6 +356,11 @@ class Builder:
         if (x.C != cin or (kh, kw, cin, c1) != (3, 3, 64, 64) or stride != 1 or int(padding) != 1 or x.W > 63
                 or n2 not in (256, 512) or k2.shape[:3] != (1, 1, c1) or os.environ.get("TFIMM_NO_CHAIN", "0") == "1"):
             return None
+        if shortcut_conv is not None:
+            x0, kds, _ = shortcut_conv
+            if (residual is not None or self.wget(kds).shape != (1, 1, 64, n2) or x0.C != 64 or x0.rows != x.rows
+                    or (act1, act2) != ("relu", "relu")):
+                return None
         pad = int(padding)
         OH = (x.H + 2 * pad - kh) // stride + 1
         OW = (x.W + 2 * pad - kw) // stride + 1
@@ -367,13 +372,26 @@ class Builder:
         wt2, b2 = pack.pack_dense((k2.reshape(c1, n2) * s2.reshape(1, n2))[pack.chain_k_order(c1)], t2)
         out = p.new_tensor(OH * OW, n2, OH, OW, name=kernel2)
         consts = {"w1": p.new_const(wt1, kernel1), "b1": p.new_const(b1, kernel1 + ":bias"),
-                  "w2": p.new_const(wt2, kernel2), "b2": p.new_const(b2, kernel2 + ":bias")}
-        ins = [x] + ([residual] if residual is not None else [])
+                  "w2": p.new_const(wt2, kernel2)}
+        flops = 2 * OH * OW * (c1 * kh * kw * cin + n2 * c1)
+        ds = None
+        if shortcut_conv is not None:
+            # ``shortcut_conv = (block input, kernel, bn)``: a 1x1 / stride 1 shortcut convolution of a 64-channel block input
+            # (first block of a stage) multiplied inside this launch; its folded-BN shift joins b2
+            x0, kds, bnds = shortcut_conv
+            wds = self.wget(kds)
+            sds, tds = self.bn(bnds, bn_eps)
+            b2 = (b2 + tds).astype(np.float32)
+            consts["ds_w"] = p.new_const(pack.pack_chain_ds(wds.reshape(64, n2) * sds.reshape(1, n2)), kds + ":frag")
+            flops += 2 * OH * OW * 64 * n2
+            ds = x0
+        consts["b2"] = p.new_const(b2, kernel2 + (":bias+shortcut" if ds is not None else ":bias"))
+        ins = [x] + ([residual] if residual is not None else []) + ([ds] if ds is not None else [])
         if residual is not None:
             assert residual.rows == OH * OW and residual.C == n2
         p.add("conv_chain", ins, out, consts, cite=cite, H=x.H, W=x.W, Cin=cin, KH=kh, KW=kw, stride=stride, pad=pad,
               OH=OH, OW=OW, C1=c1, N2=n2, ldw1=wt1.shape[1], ldw2=wt2.shape[1], act1=act1, act2=act2,
-              has_residual=residual is not None, flops=2 * OH * OW * (c1 * kh * kw * cin + n2 * c1))
+              has_residual=residual is not None, has_ds=ds is not None, flops=flops)
         return out
 
     def grouped_conv3x3(self, x: TRef, kernel: str, groups: int, *, stride=1, bn: Optional[str] = None, bn_eps=1e-5,
@@ -982,6 +1000,8 @@ class Plan:
                 d.w1, d.b1 = self.cptr(op.consts["w1"]), self.cptr(op.consts["b1"])
                 d.w2, d.b2 = self.cptr(op.consts["w2"]), self.cptr(op.consts["b2"])
                 d.residual = self.tptr(op.inputs[1]) if a["has_residual"] else None
+                if a.get("has_ds"):
+                    d.ds_x, d.ds_w, d.ds_cin = self.tptr(op.inputs[-1]), self.cptr(op.consts["ds_w"]), 64
                 d.out = self.tptr(op.output)
                 d.B, d.H, d.W, d.Cin, d.KH, d.KW = B, a["H"], a["W"], a["Cin"], a["KH"], a["KW"]
                 d.stride, d.pad_t, d.pad_l, d.OH, d.OW = a["stride"], a["pad"], a["pad"], a["OH"], a["OW"]

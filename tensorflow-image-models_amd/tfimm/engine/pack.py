@@ -211,3 +211,15 @@ def pack_stem_frag(kernel: np.ndarray, cpad: int) -> np.ndarray:
     ch4 = np.broadcast_to((j % 4)[None, None, :], tap.shape)
     col = 32 * np.arange(cpad // 32)[:, None, None, None] + (lane & 31)[None, None, :, None]                # [cc][1][64][1]
     return to_bf16_bits(full[tap[None], ch4[None], col])
+
+
+def pack_chain_ds(w: np.ndarray) -> np.ndarray:
+    """Shortcut 1x1 convolution of a bottleneck block, ``w[64][N2]`` (BN scale folded), as the MFMA A fragments the fused
+    tail kernel multiplies with the block input (tfimm_chain_desc.ds_w): uint16 [N2/32][4][64][8], element
+    [blk][t][lane][e] = w[16 t + 8 (lane >> 5) + e][32 blk + (lane & 31)]."""
+    cin, n2 = w.shape
+    assert cin == 64 and n2 % 32 == 0
+    lane = np.arange(64)
+    k = 16 * np.arange(4)[:, None, None] + 8 * (lane >> 5)[None, :, None] + np.arange(8)[None, None, :]      # [4][64][8]
+    col = 32 * np.arange(n2 // 32)[:, None, None, None] + (lane & 31)[None, None, :, None]                   # [blk][1][64][1]
+    return to_bf16_bits(np.asarray(w, np.float32)[k[None], col])

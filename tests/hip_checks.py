@@ -1114,6 +1114,40 @@ CASES["chain_n512"] = lambda: _chain_case(3, 14, 14, 64, 512, 1, 187)           
 CASES["chain_single_image_1x1"] = lambda: _chain_case(3, 1, 1, 64, 256, 1, 188)                # every tap but the centre masked
 
 
+def _chain_ds_case(B, Hh, Ww, N2, seed):
+    """fused bottleneck tail whose shortcut is a 1x1 convolution of the 64-channel block input, multiplied inside the launch
+    (first block of ResNet stage 1): against conv2 -> relu -> conv3 + shortcut convolution -> relu in fp32"""
+    import hip_ops as H
+    r = _rng(seed)
+    C1 = 64
+    y1 = _bf(r.standard_normal((B, Hh, Ww, C1)))                    # conv1 output = the tail's input
+    x0 = _bf(r.standard_normal((B, Hh, Ww, 64)))                    # block input = the shortcut convolution's input
+    k1 = (r.standard_normal((3, 3, C1, C1)) / math.sqrt(9 * C1)).astype(np.float32)
+    s1, t1 = r.uniform(0.5, 1.5, C1).astype(np.float32), r.standard_normal(C1).astype(np.float32)
+    k2 = (r.standard_normal((1, 1, C1, N2)) / math.sqrt(C1)).astype(np.float32)
+    s2, t2 = r.uniform(0.5, 1.5, N2).astype(np.float32), r.standard_normal(N2).astype(np.float32)
+    kd = (r.standard_normal((1, 1, 64, N2)) / 8).astype(np.float32)
+    sd, td = r.uniform(0.5, 1.5, N2).astype(np.float32), r.standard_normal(N2).astype(np.float32)
+    wt1, b1, K1, mode = pack.pack_conv(k1, s1, t1, C1)
+    wt2, b2 = pack.pack_dense((k2.reshape(C1, N2) * s2.reshape(1, N2))[pack.chain_k_order(C1)], t2 + td)
+    wds = pack.pack_chain_ds(kd.reshape(64, N2) * sd.reshape(1, N2))
+    mid = O.conv2d(O.zero_pad2d(torch.from_numpy(y1), 1), torch.from_numpy(_bf(k1 * s1.reshape(1, 1, 1, -1))), None)
+    mid = torch.from_numpy(_bf(torch.relu(mid + torch.from_numpy(t1)).numpy()))
+    y = O.conv2d(mid, torch.from_numpy(_bf(k2 * s2.reshape(1, 1, 1, -1)))) + torch.from_numpy(t2)
+    y = y + O.conv2d(torch.from_numpy(x0), torch.from_numpy(_bf(kd * sd.reshape(1, 1, 1, -1)))) + torch.from_numpy(td)
+    y = torch.relu(y).numpy()
+    got = H.conv_chain(H.dev_bf16(y1), H.dev_bits(wt1), H.dev_f32(b1), H.dev_bits(wt2), H.dev_f32(b2), None, KH=3, KW=3, stride=1,
+                       pad=1, OH=Hh, OW=Ww, C1=C1, N2=N2, ds_x=H.dev_bf16(x0.reshape(-1, 64)), ds_w=H.dev_bits(wds))
+    H.sync()
+    return _err(_cpu(got).reshape(B, Hh, Ww, N2), y), TOL_BF16
+
+
+CASES["chain_shortcut_conv_56x56_b3"] = lambda: _chain_ds_case(3, 56, 56, 256, 190)
+CASES["chain_shortcut_conv_odd_31x17"] = lambda: _chain_ds_case(2, 31, 17, 256, 191)
+CASES["chain_shortcut_conv_multiround_b40"] = lambda: _chain_ds_case(40, 56, 56, 256, 192)
+CASES["chain_shortcut_conv_n512"] = lambda: _chain_ds_case(3, 14, 14, 512, 193)
+
+
 def _grouped_case(B, Hh, Ww, Cc, groups, stride, seed, act="relu"):
     import hip_ops as H
     r = _rng(seed)

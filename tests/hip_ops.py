@@ -314,7 +314,8 @@ def eca_gate(sums, inv_count, w, gate_act="sigmoid"):
     return gate
 
 
-def conv_chain(x, wt1, b1, wt2, b2, residual, *, KH, KW, stride, pad, OH, OW, C1, N2, act1="relu", act2="relu"):
+def conv_chain(x, wt1, b1, wt2, b2, residual, *, KH, KW, stride, pad, OH, OW, C1, N2, act1="relu", act2="relu", ds_x=None,
+               ds_w=None):
     B, H, W, Cin = x.shape
     d = ffi.ChainDesc()
     out = torch.empty(B * OH * OW, N2, dtype=torch.bfloat16, device=DEV)
@@ -322,6 +323,8 @@ def conv_chain(x, wt1, b1, wt2, b2, residual, *, KH, KW, stride, pad, OH, OW, C1
     d.B, d.H, d.W, d.Cin, d.KH, d.KW, d.stride, d.pad_t, d.pad_l, d.OH, d.OW = B, H, W, Cin, KH, KW, stride, pad, pad, OH, OW
     d.C1, d.N2, d.ldw1, d.ldw2, d.ldr, d.ldc = C1, N2, wt1.shape[1], wt2.shape[1], N2, N2
     d.act1, d.act2 = ffi.ACT[act1], ffi.ACT[act2]
+    if ds_x is not None:
+        d.ds_x, d.ds_w, d.ds_cin = ptr(ds_x), ptr(ds_w), ds_x.shape[-1]
     ffi.check(lib.tfimm_hip_conv_chain(C.byref(d), stream()), "conv_chain")
     return out
 

@@ -119,8 +119,10 @@ def test_resnet50_stage1_tails_are_one_launch_each():
     64-channel intermediate never reaches HBM); the algorithmic FLOP count is unchanged; TFIMM_NO_CHAIN=1 keeps two GEMMs"""
     kinds, prog = _kinds("resnet50")
     chains = [op for op in prog.ops if op.kind == "conv_chain"]
-    assert len(chains) == 3 and all((op.attrs["H"], op.attrs["C1"], op.attrs["N2"], op.attrs["has_residual"]) == (56, 64, 256, True)
-                                    for op in chains)
+    assert len(chains) == 3 and all((op.attrs["H"], op.attrs["C1"], op.attrs["N2"]) == (56, 64, 256) for op in chains)
+    # the first block's shortcut convolution (64 -> 256 on the stem output) is multiplied inside its tail: no launch, no tensor
+    assert [(op.attrs["has_residual"], bool(op.attrs.get("has_ds"))) for op in chains] == [(False, True), (True, False), (True, False)]
+    assert not [op for op in prog.ops if op.kind == "gemm" and op.attrs.get("K") == 64 and op.attrs["N"] == 256]
     assert abs(prog.flops_per_image() / 1e9 - 8.178) < 0.01
     kinds, _ = _kinds("resnet50", size=(256, 256))          # rows of 64 pixels: wider than the kernel's input strip
     assert "conv_chain" not in kinds
