@@ -214,6 +214,7 @@ __global__ void __launch_bounds__(256, 2) gemm_chain_kernel(const ChainArgs p) {
   // everything issued behind that DMA: the rest of step s - 3 and all of steps s - 2 and s - 1.
   struct Ops {
     static constexpr int all(int r) {           // r = position in the tile program
+      if (DS && r == NK1 - 2) return B1_INSTR + TN1 * 4;      // DS: the GEMM-1 bias quads are fetched here, per tile
       if (r < NK1 - 1) return B1_INSTR;
       if (r == NK1 - 1) return EPI_LOADS + DS_X + B1_INSTR;
       const int u = r - NK1;
@@ -234,16 +235,23 @@ __global__ void __launch_bounds__(256, 2) gemm_chain_kernel(const ChainArgs p) {
   static_assert(Ops::wait_for(NK1 + NS2 - 1) < 64, "vmcnt is a 6-bit counter");
 
   // bias of GEMM 1 in the accumulator layout: lane owns channels j*32 + q*8 + fhi*4 .. +3
+  // (DS flavour: these 32 registers are what pushes it over the budget while GEMM 2 and the shortcut fragments are live, so it
+  // fetches them per tile instead, behind tap 7 -- eight L2 hits that are back long before epilogue 1)
   f32x4 bias1[TN1][4];
+  auto load_bias1 = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int j = 0; j < TN1; ++j)
+    for (int j = 0; j < TN1; ++j)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 b4 = *reinterpret_cast<const float4*>(p.b1 + j * 32 + q * 8 + fhi * 4);
-      bias1[j][q] = f32x4{b4.x, b4.y, b4.z, b4.w};
-    }
-  // their values must be in registers before the counted waits below start leaving operations in flight
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias1[0][0]), "+v"(bias1[0][3]), "+v"(bias1[TN1 - 1][0]), "+v"(bias1[TN1 - 1][3])::"memory");
+      for (int q = 0; q < 4; ++q) {
+        const float4 b4 = *reinterpret_cast<const float4*>(p.b1 + j * 32 + q * 8 + fhi * 4);
+        bias1[j][q] = f32x4{b4.x, b4.y, b4.z, b4.w};
+      }
+  };
+  if constexpr (!DS) {
+    load_bias1();
+    // their values must be in registers before the counted waits below start leaving operations in flight
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias1[0][0]), "+v"(bias1[0][3]), "+v"(bias1[TN1 - 1][0]), "+v"(bias1[TN1 - 1][3])::"memory");
+  }
 
   if (p.dbg & 8) {
     const int n = ((blockIdx.x >> 3) & 7) * (p.dbg >> 8);
@@ -315,6 +323,7 @@ __global__ void __launch_bounds__(256, 2) gemm_chain_kernel(const ChainArgs p) {
       else chain_wait_vm<Ops::wait_for(k)>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      if constexpr (DS && k == NK1 - 2) { load_bias1(); __builtin_amdgcn_sched_barrier(0); }
       if constexpr (k == NK1 - 1) {
         load_epi(ChainIdx<0>{});
         if constexpr (DS) {
