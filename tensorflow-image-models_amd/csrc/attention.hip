@@ -669,12 +669,19 @@ __global__ void __launch_bounds__(NW * 64) attn_stream_kernel(const AttnArgs p, 
       l_run[u] = 0.f;
     }
     if (active) {
+      // One block of 64 keys per iteration.  In the last block, when n is not a multiple of 64, only the first `nt` 16-key
+      // sub-tiles hold keys (n = 197: one of four): the score MFMAs, the exponentials and the P.V k-steps of the others are
+      // skipped (wave-uniform branches); what they would have contributed are exact zeros (P = 0), so the result is
+      // bit-identical to multiplying the padding.
       for (int kb = (p.dbg & 1) ? nkb : 0; kb < nkb; ++kb) {
+        const int nt = min(4, (p.n - kb * 64 + 15) >> 4);      // wave-uniform
+        const bool PART = nt < 4 || kb * 64 + 64 > p.n;
         f32x4 acc[TQ][4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
           for (int u = 0; u < TQ; ++u) acc[u][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (PART && t >= nt) continue;
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
             const bf16x8 kf = __builtin_bit_cast(bf16x8, Ks[k_slot<HD>(kb * 64 + t * 16 + l15, ks * 4 + g)]);
@@ -692,7 +699,7 @@ __global__ void __launch_bounds__(NW * 64) attn_stream_kernel(const AttnArgs p, 
           for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) sc[t * 4 + r] = acc[u][t][r];
-          if (kb * 64 + 64 > p.n) {   // last block: keys beyond n never win the max and get p = 0
+          if (PART) {   // keys beyond n never win the max and get p = 0
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -710,9 +717,17 @@ __global__ void __launch_bounds__(NW * 64) attn_stream_kernel(const AttnArgs p, 
           const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);
           float psum = 0.f;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            sc[i] = __builtin_amdgcn_exp2f(fmaf(sc[i], cs, -m_new));
-            psum += sc[i];
+          for (int t = 0; t < 4; ++t) {
+            if (PART && t >= nt) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) sc[t * 4 + r] = 0.f;
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                sc[t * 4 + r] = __builtin_amdgcn_exp2f(fmaf(sc[t * 4 + r], cs, -m_new));
+                psum += sc[t * 4 + r];
+              }
+            }
           }
           l_run[u] = l_run[u] * alpha + psum;
           m_run[u] = m_new;
@@ -732,6 +747,7 @@ __global__ void __launch_bounds__(NW * 64) attn_stream_kernel(const AttnArgs p, 
         typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
+          if (PART && 2 * s2 >= nt) continue;
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
             const int krow = kb * 64 + g * 4 + (l15 >> 2);

@@ -689,6 +689,46 @@ def _dw_case(B, H, W, Cc, k, stride, padding, act, seed):
     return max(e, es / 10), TOL_BF16
 
 
+
+
+def _act_saturation_case(act, seed):
+    """Sigmoid-class activations far outside their usual range: pre-activations of +-25 ... +-3e4, where exp overflows to
+    inf or underflows to 0, must give the saturated value -- never NaN.  (A variant of the packed epilogue that shared one
+    reciprocal among four denominators 1 + 2^z needed a clamp on z for exactly this; it was slower and is gone, the case
+    stays.)  Checked element by element (a bf16 rounding of the exact value, 2e-6 absolute, 1e-9 |v| for a clamped tail),
+    through the GEMM epilogue (bias carries the values, the product contributes 0) and through the depthwise kernel."""
+    import hip_ops as Hh
+    r = _rng(seed)
+    vals = np.concatenate([np.linspace(-150, 150, 301), [-3e4, -1e3, -88.8, -24.1, -16.7, 16.7, 24.1, 88.8, 1e3, 3e4],
+                           r.standard_normal(201) * 3]).astype(np.float32)
+    N = vals.size
+    M, K = 300, 16
+    a = np.zeros((M, K), np.float32)
+    wt, _ = pack.pack_dense(_bf(r.standard_normal((K, N))), None)
+    got = _cpu(Hh.gemm(Hh.dev_bf16(a), Hh.dev_bits(wt), N, K, bias=Hh.dev_f32(vals), act=act))
+    ref = O.activation(torch.from_numpy(vals), act).numpy().astype(np.float64)
+    Hh.sync()
+    assert np.all(np.isfinite(got)), "non-finite activation output"
+    tol = np.abs(ref) * 2.0 ** -8 + 2e-6 + np.abs(vals.astype(np.float64)) * 1e-9      # last term: the clamped tail (s >= 2^-31)
+    worst = float(np.max(np.abs(got.astype(np.float64) - ref[None]) / tol[None]))
+    # depthwise 3x3 with a centre tap of 0 and the values as the per-channel shift: act(shift) at every pixel
+    Cc = (N + 7) // 8 * 8
+    sh = np.zeros(Cc, np.float32)
+    sh[:N] = vals
+    w, bias = pack.pack_depthwise(np.zeros((3, 3, Cc, 1), np.float32), np.ones(Cc, np.float32), sh)
+    x = _bf(r.standard_normal((2, 9, 9, Cc)))
+    gd = _cpu(Hh.dwconv(Hh.dev_bf16(x), Hh.dev_f32(w), Hh.dev_f32(bias), 3, 1, 1, 1, 9, 9, act=act)[0])
+    Hh.sync()
+    assert np.all(np.isfinite(gd)), "non-finite activation output (depthwise)"
+    refd = O.activation(torch.from_numpy(sh), act).numpy().astype(np.float64)
+    told = np.abs(refd) * 2.0 ** -8 + 2e-6 + np.abs(sh.astype(np.float64)) * 1e-9
+    worst = max(worst, float(np.max(np.abs(gd.astype(np.float64) - refd) / told)))
+    return worst, 1.0
+
+
+for _a in ("swish", "sigmoid", "tanh"):
+    CASES[f"act_saturation_{_a}"] = (lambda a=_a: _act_saturation_case(a, 410))
+
 CASES["dwconv_k3_s1_same_c48"] = lambda: _dw_case(2, 19, 19, 48, 3, 1, "same", "swish", 90)
 CASES["dwconv_k3_s2_same_even"] = lambda: _dw_case(2, 20, 20, 144, 3, 2, "same", "swish", 91)
 CASES["dwconv_k5_s2_same_odd"] = lambda: _dw_case(2, 15, 15, 32, 5, 2, "same", "swish", 92)
