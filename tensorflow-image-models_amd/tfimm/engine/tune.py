@@ -32,10 +32,12 @@ def autotune_enabled() -> bool:
 def key_of(d) -> str:
     """Everything that changes the kernel's work: GEMM extents, operand strides, conv geometry and
     the epilogue flavour (residual / fp32 output change the epilogue's memory traffic) and the SE-gate
-    prologue."""
-    return ":".join(str(int(v)) for v in (
+    prologue.  A layer with a folded LayerNormalization (``ln_stats``: other kernel flavour, longer epilogue, only
+    the persistent tiles) gets an entry of its own, ``...:ln``."""
+    key = ":".join(str(int(v)) for v in (
         d.mode, d.M, d.N, d.K, d.lda, d.ldc, d.H, d.W, d.Cin, d.KH, d.KW, d.stride,
         1 if d.residual else 0, d.out_f32, d.act, 1 if d.a_scale else 0))
+    return key + ":ln" if getattr(d, "ln_stats", None) else key
 
 
 def lookup(d) -> int:
