@@ -21,5 +21,8 @@ for m in resnet50 vit_base_patch16_224 swin_base_patch4_window7_224 efficientnet
   rm -rf $O/prof_$m
 done
 cd $R
+for m in resnet50 vit_base_patch16_224 swin_base_patch4_window7_224 efficientnet_b4; do
+  timeout 300 python tools/op_profile.py $m > $O/opprof_$m.log 2>&1; echo "opprof $m rc=$?"; head -1 $O/opprof_$m.txt
+done
 bash tools/gpu_traffic.sh > $O/traffic.log 2>&1; tail -12 $O/traffic.log
 rm -rf $O/traffic_FETCH_SIZE $O/traffic_WRITE_SIZE

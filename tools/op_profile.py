@@ -50,6 +50,16 @@ def op_bytes_flops(op, prog, B):
     if k == "dwconv":
         byts = B * (a["H"] * a["W"] + a["OH"] * a["OW"]) * a["C"] * 2
         return byts, 2.0 * B * a["OH"] * a["OW"] * a["C"] * a["k"] ** 2, f"C={a['C']} k={a['k']} s={a['stride']} {a['H']}->{a['OH']}"
+    if k == "conv_chain":
+        M = B * a["OH"] * a["OW"]
+        byts = B * a["H"] * a["W"] * a["Cin"] * 2 + (a["C1"] * a["ldw1"] + a["N2"] * a["ldw2"]) * 2 + M * a["N2"] * 2
+        if a.get("has_residual"):
+            byts += M * a["N2"] * 2
+        if a.get("has_ds"):
+            byts += M * a["Cin"] * 2 + a["N2"] * a["Cin"] * 2
+        return byts, float(a["flops"]) * B, (f"M={M} 3x3 {a['Cin']}->{a['C1']} -> 1x1 ->{a['N2']}" +
+                                             (" +res" if a.get("has_residual") else "") +
+                                             (" +shortcut conv" if a.get("has_ds") else "") + " (fused bottleneck tail)")
     if k == "expand_dwconv":
         byts = B * (a["H"] * a["W"] * a["Cin"] + a["OH"] * a["OW"] * a["C"]) * 2
         return byts, float(a["flops"]) * B, f"{a['Cin']}->{a['C']} k={a['k']} s={a['stride']} {a['H']}->{a['OH']} (fused expand + dw)"
