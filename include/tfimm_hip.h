@@ -206,7 +206,8 @@ TFIMM_API int tfimm_hip_layernorm(const void* x, void* y, const float* gamma, co
 /* ---------------------------------------------------------------------------------------
  * tfimm_hip_attention: fused softmax(scale * Q K^T [+ bias] [+ mask]) V per (sequence, head),
  * reading q/k/v straight out of the packed QKV projection  qkv[row][3][heads][hd]  and
- * writing out[row][heads*hd].  fp32 softmax, bf16 P.
+ * writing out[row][heads*hd].  fp32 softmax, bf16 P.  Head dims: global attention 1..128 (vit_huge_patch14: 80),
+ * windows 1..64; anything else returns TFIMM_EUNSUP.
  *
  * window == 0: global attention, sequence s = image, token t -> row s*n_tokens + t.
  *     Replaces vit.py:156-167 (reshape/transpose, scale*matmul, softmax, matmul, merge).

@@ -994,7 +994,8 @@ extern "C" int tfimm_hip_attention(const tfimm_attn_desc* dp, void* stream) {
   if (!d.qkv || !d.out) TFIMM_FAIL(TFIMM_EINVAL, "attention: null pointer");
   if (d.batch <= 0 || d.n_tokens <= 0 || d.heads <= 0 || d.hd <= 0)
     TFIMM_FAIL(TFIMM_EINVAL, "attention: bad shape");
-  if (d.hd > 64) TFIMM_FAIL(TFIMM_EUNSUP, "attention: head dim %d > 64 not built", d.hd);
+  if (d.hd > 128) TFIMM_FAIL(TFIMM_EUNSUP, "attention: head dim %d > 128 not built", d.hd);
+  if (d.hd > 64 && d.window > 0) TFIMM_FAIL(TFIMM_EUNSUP, "attention: windows with head dim %d > 64 not built", d.hd);
   AttnArgs a;
   a.qkv = (const bf16_t*)d.qkv; a.out = (bf16_t*)d.out; a.rel_bias = d.rel_bias;
   a.bias_log2 = d.window > 0 ? d.bias_log2 : nullptr;
@@ -1024,6 +1025,13 @@ extern "C" int tfimm_hip_attention(const tfimm_attn_desc* dp, void* stream) {
   if (nblocks > 0x7fffffffLL) TFIMM_FAIL(TFIMM_EINVAL, "attention: grid too large");
   const dim3 grid((unsigned)nblocks), block(256);
   hipStream_t st = (hipStream_t)stream;
+  if (d.hd > 64) {
+    // head dims 65..128 (vit_huge_patch14: 80): the streaming kernel with three / four MFMA k-steps over the head dimension
+    // and six / eight output tiles per wave; the columns beyond hd are zero in K, Q and V
+    if (d.hd <= 96) TFIMM_LAUNCH((attn_kernel<96, false>), grid, block, 0, st, a);
+    else TFIMM_LAUNCH((attn_kernel<128, false>), grid, block, 0, st, a);
+    return 0;
+  }
   {
     // K + V^T (+ Swin bias tile) of one (sequence, head) resident in LDS (<= 80 KiB: two workgroups per CU)
     const bool tl = d.window > 0 && d.bias_log2 != nullptr;

@@ -390,6 +390,11 @@ CASES["attn_577_hd64"] = lambda: _attn_case(1, 577, 2, 64, 64)
 CASES["attn_mini_17_hd2"] = lambda: _attn_case(3, 17, 2, 2, 65)
 CASES["attn_50_hd32"] = lambda: _attn_case(2, 50, 4, 32, 66)
 CASES["attn_hd48"] = lambda: _attn_case(2, 33, 2, 48, 67)
+# head dims above 64 (vit_huge_patch14_224_in21k: 1280 / 16 = 80): three / four k-steps over the head dimension
+CASES["attn_257_hd80_vit_huge"] = lambda: _attn_case(2, 257, 16, 80, 270)
+CASES["attn_70_hd96"] = lambda: _attn_case(2, 70, 3, 96, 271)
+CASES["attn_197_hd128"] = lambda: _attn_case(1, 197, 2, 128, 272)
+CASES["attn_33_hd72_spike"] = lambda: _attn_case(2, 33, 2, 72, 273, spike=True)
 
 
 def _tha_ref(qkv, B, N, heads, hd, scale, wl, bl, ww, bw):

@@ -76,6 +76,12 @@ if not is_model("vit_test_model"):
                               embed_dim=128, nb_blocks=2, nb_heads=2, representation_size=24)
 
     @register_model
+    def vit_hd80_test_model():
+        """Head dim 80 as in vit_huge_patch14_224_in21k (1280 / 16), patch 14, 17 tokens."""
+        return ViT, ViTConfig(name="vit_hd80_test_model", nb_classes=10, input_size=(56, 56), patch_size=14,
+                              embed_dim=160, nb_blocks=2, nb_heads=2)
+
+    @register_model
     def resnet50_mini_test_model():
         return ResNet, ResNetConfig(name="resnet50_mini_test_model", nb_classes=10, input_size=(64, 64),
                                     block="bottleneck", nb_blocks=(1, 2, 1, 1), nb_channels=(8, 16, 24, 32))

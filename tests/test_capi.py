@@ -46,8 +46,8 @@ def test_descriptor_validation_without_gpu():
     assert ffi.lib.tfimm_hip_gemm(ctypes.byref(d), None) == -1
     at = ffi.AttnDesc()
     at.qkv = at.out = a.data_ptr()
-    at.batch, at.n_tokens, at.heads, at.hd = 1, 16, 1, 128
-    assert ffi.lib.tfimm_hip_attention(ctypes.byref(at), None) == -2      # head dim > 64: not built
+    at.batch, at.n_tokens, at.heads, at.hd = 1, 16, 1, 136
+    assert ffi.lib.tfimm_hip_attention(ctypes.byref(at), None) == -2      # head dim > 128: not built
 
 
 def test_gemm_desc_layout_matches_header():

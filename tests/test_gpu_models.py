@@ -7,7 +7,7 @@ import test_architectures  # noqa: F401  (registers the miniature configs)
 
 pytestmark = pytest.mark.gpu
 
-MINIS = ["vit_test_model", "deit_test_model", "vit_hd64_test_model", "resnet_test_model_1", "resnet_test_model_2",
+MINIS = ["vit_test_model", "deit_test_model", "vit_hd64_test_model", "vit_hd80_test_model", "resnet_test_model_1", "resnet_test_model_2",
          "resnet50_mini_test_model", "seresnet_test_model", "swin_test_model", "swin_shift_test_model",
          "efficientnet_test_model", "efficientnet_same_test_model", "convnext_odd_test_model", "convnext_wide_test_model",
          "cait_hd48_test_model", "cait_hd32_test_model", "resnetd_test_model", "resnext_test_model", "resnext_wide_test_model",

@@ -1,6 +1,6 @@
 """Forward every registered configuration (below a parameter budget) once on the GPU with the synthetic weights and save
 the logits -- tools/sweep_check.py compares them with the fp32 oracle on a CPU box.
-    python tools/sweep_forward.py [max_params_millions] [name_filter]"""
+    python tools/sweep_forward.py [max_params_millions] [name_filter] [min_params_millions]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tensorflow-image-models_amd"), os.path.join(ROOT, "tests")):
@@ -12,6 +12,7 @@ import model_checks as mc
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
+floor = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
 out = os.path.join(ROOT, "gpurun_out", "sweep")
 os.makedirs(out, exist_ok=True)
 names = [n for n in tfimm.list_models() if flt in n]
@@ -21,7 +22,7 @@ for name in names:
     try:
         m = tfimm.create_model(name)
         nparams = sum(int(np.prod(s.shape)) for s in m.weight_specs().values())
-        if nparams > budget * 1e6:
+        if nparams > budget * 1e6 or nparams <= floor * 1e6:
             skipped += 1
             continue
         m.set_weights(synthetic_weights(m, 2021))
