@@ -11,6 +11,7 @@ import model_checks as mc
 
 d = os.path.join(ROOT, "gpurun_out", "sweep")
 rows = []
+conditioned = []      # above the bar, but no further from the oracle than the oracle is from itself under bf16 weight rounding
 for f in sorted(glob.glob(os.path.join(d, "*.npy"))):
     name = os.path.basename(f)[:-4]
     if len(sys.argv) > 1 and sys.argv[1] not in name:
@@ -23,10 +24,24 @@ for f in sorted(glob.glob(os.path.join(d, "*.npy"))):
     got = np.load(f).reshape(ref.shape)
     err = mc.rel_err(got, ref)
     agree = float((got.argmax(-1) == ref.argmax(-1)).mean())
+    note = ""
+    if err > mc.TOL_LOGITS:
+        # Is it the engine or the problem?  The SAME fp32 oracle with its convolution / dense kernels and its input rounded to
+        # bf16 (what the engine stores; nothing else changed): a random-init network of ~100 layers can amplify that rounding
+        # alone beyond the bar (efficientnet_v2_xl: 0.34-0.49), and then the bar says nothing about the kernels.
+        import torch
+        def bf(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(torch.bfloat16).float().numpy()
+        w2 = {k: (bf(v) if k.split(":")[0].endswith("kernel") and v.ndim >= 2 else v) for k, v in w.items()}
+        cond = mc.rel_err(oracle.forward(m.cfg, w2, bf(np.asarray(x, dtype=np.float32))), ref)
+        note = f"  [oracle with bf16-rounded kernels + input vs itself: {cond:.3e}]"
+        if err <= 2 * cond:
+            conditioned.append(name)
     rows.append((err, name, agree))
-    print(f"{name:45s} rel-to-max {err:.3e} top1 {agree:.2f}  ({time.time() - t0:.0f} s)", flush=True)
+    print(f"{name:45s} rel-to-max {err:.3e} top1 {agree:.2f}  ({time.time() - t0:.0f} s){note}", flush=True)
 errs = sorted(rows, reverse=True)
 print("\nworst:", [(n, f"{e:.2e}") for e, n, _ in errs[:8]])
-print(f"{len(rows)} models, {sum(e <= mc.TOL_LOGITS for e, _, _ in rows)} within {mc.TOL_LOGITS}")
+print(f"{len(rows)} models, {sum(e <= mc.TOL_LOGITS for e, _, _ in rows)} within {mc.TOL_LOGITS}"
+      + (f"; above it but within 2x the oracle's own sensitivity to bf16-rounded kernels: {conditioned}" if conditioned else ""))
 for f in sorted(glob.glob(os.path.join(d, "*.err"))):
     print("ERROR", os.path.basename(f), open(f).read().strip()[:200])
