@@ -1155,7 +1155,7 @@ class Plan:
                 continue
             best, best_ms = 0, float("inf")
             times = self._tune_times.setdefault(key, {})
-            for hint in tune.CANDIDATES:
+            for hint in tune.candidates_for(d):
                 d.tile_hint = hint
                 if lib.tfimm_hip_gemm(C.byref(d), st) != 0:
                     continue

@@ -16,6 +16,8 @@ import os
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tune.json")
 CANDIDATES = (0, 21, 22, 23, 24, 25, 26, 27, 28, 29, 11, 12, 13, 14, 15, 16)
+# a layer with a folded LayerNormalization runs on the persistent tiles only (the library ignores any other hint for it)
+LN_CANDIDATES = (0, 21, 22, 23, 24, 25, 26, 27, 29)
 TABLE = {}
 _autotune = os.environ.get("TFIMM_AUTOTUNE", "0") == "1"
 
@@ -38,6 +40,10 @@ def key_of(d) -> str:
         d.mode, d.M, d.N, d.K, d.lda, d.ldc, d.H, d.W, d.Cin, d.KH, d.KW, d.stride,
         1 if d.residual else 0, d.out_f32, d.act, 1 if d.a_scale else 0))
     return key + ":ln" if getattr(d, "ln_stats", None) else key
+
+
+def candidates_for(d):
+    return LN_CANDIDATES if getattr(d, "ln_stats", None) else CANDIDATES
 
 
 def lookup(d) -> int:

@@ -1,0 +1,43 @@
+"""CPU: the GEMM tile table (tfimm/engine/tune.py, gemm_tune.json) -- key format, hint ranges, LayerNorm-folded layers keyed apart."""
+import json
+import os
+
+from tfimm.engine import ffi, tune
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TABLE = os.path.join(ROOT, "tensorflow-image-models_amd", "tfimm", "engine", "gemm_tune.json")
+
+
+def _desc(**kw):
+    d = ffi.GemmDesc()
+    d.mode, d.M, d.N, d.K, d.lda, d.ldc = 0, 100864, 2304, 768, 768, 2304
+    for k, v in kw.items():
+        setattr(d, k, v)
+    return d
+
+
+def test_key_covers_shape_epilogue_and_ln_flavour():
+    base = tune.key_of(_desc())
+    assert base.count(":") == 15 and not base.endswith(":ln")
+    assert tune.key_of(_desc(act=ffi.ACT["gelu"])) != base                  # epilogue flavour
+    assert tune.key_of(_desc(residual=0x1000)) != base
+    assert tune.key_of(_desc(a_scale=0x1000)) != base
+    ln = tune.key_of(_desc(ln_stats=0x1000, ln_c1=0x2000))
+    assert ln == base + ":ln"                                             # same shape, other kernel flavour: own entry
+    assert tune.key_of(_desc(M=100865)) != base
+
+
+def test_committed_table_is_well_formed():
+    table = json.load(open(TABLE))
+    assert len(table) >= 150
+    valid = {0} | set(range(1, 7)) | set(range(11, 17)) | set(range(21, 30))
+    for key, hint in table.items():
+        fields = key[:-3].split(":") if key.endswith(":ln") else key.split(":")
+        assert len(fields) == 16 and all(f.lstrip("-").isdigit() for f in fields), key
+        assert hint in valid, (key, hint)
+        if key.endswith(":ln"):
+            # only the persistent LDS-DMA tiles carry the LayerNorm epilogue (28 = the deep-ring schedule does not)
+            assert hint == 0 or (21 <= hint <= 29 and hint != 28), (key, hint)
+    assert tune.TABLE and all(tune.TABLE[k] == v for k, v in table.items())
+    # the scored ViT-B layers with a folded LayerNorm are in it
+    assert any(k.startswith("0:100864:2304:768:") and k.endswith(":ln") for k in table)
