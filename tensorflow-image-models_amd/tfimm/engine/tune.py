@@ -42,8 +42,16 @@ def key_of(d) -> str:
     return key + ":ln" if getattr(d, "ln_stats", None) else key
 
 
+# a layer with an SE gate on its A operand: hints 11..16 send it to the register-staged family (the LDS-DMA family has no
+# gate flavour), which scales every A element once while it stages it -- for the narrow project layers of EfficientNet that
+# beats the persistent kernels (every wave there scales the fragments it reads); its six tiles are candidates of their own
+SCALE_CANDIDATES = CANDIDATES + (1, 2, 3, 4, 5, 6)
+
+
 def candidates_for(d):
-    return LN_CANDIDATES if getattr(d, "ln_stats", None) else CANDIDATES
+    if getattr(d, "ln_stats", None):
+        return LN_CANDIDATES
+    return SCALE_CANDIDATES if getattr(d, "a_scale", None) else CANDIDATES
 
 
 def lookup(d) -> int:
