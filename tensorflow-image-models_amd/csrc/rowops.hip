@@ -788,7 +788,11 @@ __global__ void __launch_bounds__(256) dwconv_rows_kernel(const bf16_t* __restri
   tfimm_sq_t* lsum = reinterpret_cast<tfimm_sq_t*>(dw7_lds + K * K * CPB);
   if (sum_out && tid < 2 * CPB) lsum[tid] = 0;
   __syncthreads();
-  tfimm_f32x2 tot = {0.f, 0.f};
+  // squeeze sums: every finished output row converts ITS partial (four pixels, fixed order) to fixed point and the thread adds
+  // integers from there on -- the sum no longer depends on how many rows a thread marches, i.e. on the row segmentation the
+  // launch picks from the batch size (a thread-long fp32 partial made batch-2 and batch-256 forwards of EfficientNet-B4 differ
+  // in the last bits of the squeeze, and through bf16 roundings further down by up to 1e-2 of the logit range)
+  long long tot0 = 0, tot1 = 0;                     // 2^-16 units
   if (live) {
 
   const int c0 = cp * 2;
@@ -866,14 +870,20 @@ __global__ void __launch_bounds__(256) dwconv_rows_kernel(const bf16_t* __restri
             static_assert(PX == 4, "the activation runs on four packed pairs");
             tfimm_f32x2 av[4] = {acc[dslot][0], acc[dslot][1], acc[dslot][2], acc[dslot][3]};
             act8p(av, actp);            // packed (v_pk_*): the scalar form cost ~33 issue slots per pair for swish, this ~21
+            tfimm_f32x2 rowtot = {0.f, 0.f};
 #pragma unroll
             for (int px = 0; px < PX; ++px) {
               const uint32_t pk = pack_bf2(av[px][0], av[px][1]);
               if (ox0 + px < OW) {
                 *reinterpret_cast<uint32_t*>(yrow + (size_t)(ox0 + px) * C) = pk;
                 // the squeeze sees the stored (bf16-rounded) activations
-                tot += tfimm_f32x2{__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)};
+                rowtot += tfimm_f32x2{__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)};
               }
+            }
+            if (sum_out) {               // (wave-uniform) |row partial| < 32768: v_cvt_i32_f32 saturates beyond
+              rowtot *= 65536.f;
+              tot0 += (long long)__float2int_rn(rowtot.x);
+              tot1 += (long long)__float2int_rn(rowtot.y);
             }
           }
 #pragma unroll
@@ -885,8 +895,8 @@ __global__ void __launch_bounds__(256) dwconv_rows_kernel(const bf16_t* __restri
   }
   if (sum_out) {
     if (live) {
-      sq_add(&lsum[2 * cpl], sq_from_float(tot.x));
-      sq_add(&lsum[2 * cpl + 1], sq_from_float(tot.y));
+      sq_add(&lsum[2 * cpl], (tfimm_sq_t)(tot0 * 16));         // 2^-16 -> 2^-20 units
+      sq_add(&lsum[2 * cpl + 1], (tfimm_sq_t)(tot1 * 16));
     }
     __syncthreads();
     if (tid < 2 * CPB && ct * CPB * 2 + tid < C) sq_add(sum_out + (size_t)b * C + ct * CPB * 2 + tid, lsum[tid]);
