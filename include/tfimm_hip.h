@@ -314,7 +314,10 @@ TFIMM_API int tfimm_hip_bcast_rows(const void* src, void* dst, int B, int n_rows
  * Optionally accumulates per-(image, channel) sums of the OUTPUT into sum_out -- the SE squeeze fused into the
  * producer: int64 [B][C] FIXED-POINT accumulators in units of 2^-20 (zeroed by the caller; read them with
  * tfimm_hip_se_gate(sums_fixed = 1)).  Integer adds commute, so the sums -- and everything computed from them -- are
- * bit-identical from launch to launch whatever order the workgroups arrive in (float atomics were not).
+ * bit-identical from launch to launch whatever order the workgroups arrive in (float atomics were not), and from batch
+ * size to batch size: a thread converts the partial sum of every finished output row (four pixels of one channel, rounded
+ * to 2^-16; partials beyond +-32768 saturate) before it adds, so the way a launch splits an image into row segments
+ * does not show in the result.
  * Replaces DepthwiseConv2D + BatchNormalization + Activation
  * (efficientnet_blocks.py:350-352,443-445; convnext.py:191-197 with act none).
  * ------------------------------------------------------------------------------------- */
