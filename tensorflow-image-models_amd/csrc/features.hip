@@ -194,9 +194,12 @@ extern "C" int tfimm_hip_group_norm(const void* x, const float* gamma, const flo
   if ((size_t)C * 16 > 64 * 1024) TFIMM_FAIL(TFIMM_EUNSUP, "group_norm: %d channels", C);
   hipStream_t st = (hipStream_t)stream;
   TFIMM_HIP_CHECK(hipMemsetAsync(stats_ws, 0, (size_t)B * groups * 2 * sizeof(tfimm_sq_t), st));
-  // enough workgroups to fill the chip, at least 8 rows each
-  int per = (int)cdiv64((int64_t)rows * B, 2048);
+  // Rows per workgroup: a function of the image size ONLY.  A thread sums its rows of a run in fp32 before it converts to fixed
+  // point, so a run length chosen from the batch size (as it was: rows * B / 2048) made the statistics -- and the logits, by
+  // up to 8e-3 at batch 32 against batch 2 -- depend on the batch.  8..64 rows: >= 2048 workgroups from batch 42 on at 56 x 56.
+  int per = (int)cdiv64(rows, 16);
   if (per < 8) per = 8;
+  if (per > 64) per = 64;
   if (per > rows) per = rows;
   const int chunks = (rows + per - 1) / per;
   const bool vec = (C & 7) == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0;

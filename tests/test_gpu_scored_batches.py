@@ -55,19 +55,23 @@ def test_scored_batch(name, batch, exact):
     assert len(picks) == 6
 
 
-@pytest.mark.parametrize("name", ["efficientnet_b0", "mobilenet_v2_100", "convnext_tiny", "cait_xxs24_224", "resnext50_32x4d",
-                                  "seresnet50", "resnet50_gn", "swin_tiny_patch4_window7_224", "deit_small_patch16_224"])
-def test_many_images_are_reproducible_and_batch_invariant(name):
+@pytest.mark.parametrize("name,batch", [(n, 64) for n in (
+    "efficientnet_b0", "mobilenet_v2_100", "convnext_tiny", "cait_xxs24_224", "resnext50_32x4d", "seresnet50", "resnet50_gn",
+    "swin_tiny_patch4_window7_224", "deit_small_patch16_224")] + [("resnet50_gn", 32), ("efficientnet_b0", 24)])
+def test_many_images_are_reproducible_and_batch_invariant(name, batch):
     """64 images keep several workgroups per CU busy at once -- where a missing barrier or an order-dependent reduction shows
     (one did: the halo staging of the fused MBConv kernel).  The eager launches of the first call, the hipGraph replays of
-    the next two and the batch-2 forward give the same bits."""
+    the next two and the batch-2 forward give the same bits.  (Batch 32 / 24 as well: GroupNorm's statistics pass and the
+    depthwise kernels used to pick their row runs from the batch size, and a thread's fp32 partial over such a run made the
+    logits batch-dependent -- at batch 32 but, by coincidence of the split, not at 64.)"""
     model = tfimm.create_model(name)
     model.set_weights(synthetic_weights(model, 2021))
     cfg = model.cfg
     g = torch.Generator(device="cuda").manual_seed(11)
-    x = torch.rand(64, *cfg.input_size, cfg.in_channels, device="cuda", generator=g).to(torch.bfloat16)
+    x = torch.rand(batch, *cfg.input_size, cfg.in_channels, device="cuda", generator=g).to(torch.bfloat16)
     runs = [model(x).numpy() for _ in range(3)]
     assert np.isfinite(runs[0]).all()
     assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[1], runs[2]), name
-    small = model(x[30:32]).numpy()
-    assert np.array_equal(small, runs[0][30:32]), (name, float(np.abs(small - runs[0][30:32]).max()))
+    lo = batch // 2 - 2
+    small = model(x[lo:lo + 2]).numpy()
+    assert np.array_equal(small, runs[0][lo:lo + 2]), (name, float(np.abs(small - runs[0][lo:lo + 2]).max()))
