@@ -35,6 +35,7 @@ REFERENCE = "/root/reference"
 
 #: (name, batch, store features?)   -- minis first (features stored), then full-size configs (logits only)
 MODELS = [("vit_test_model", 2, True), ("deit_test_model", 2, True), ("vit_hd64_test_model", 2, True),
+          ("vit_hd80_test_model", 2, True), ("resnext_wide_test_model", 2, True),
           ("resnet_test_model_1", 2, True), ("resnet_test_model_2", 2, True), ("resnet50_mini_test_model", 2, True),
           ("seresnet_test_model", 2, True), ("resnetd_test_model", 2, True), ("resnext_test_model", 2, True),
           ("ecaresnet_test_model", 2, True), ("resnetd_odd_test_model", 2, True), ("resnet_gn_test_model", 2, True),
