@@ -18,8 +18,12 @@ For every model in MODELS:
 Writes  tests/golden/forward_golden.npz      (reference-over-stand-in outputs)
         tests/golden/reference_weights.json  (variable names + shapes of reference models, incl.
                                               the build-time constants the reference never loads)
+        tests/golden/reference_weight_digests.json  (--digests: EVERY configuration the reference registers in the six
+                                              modules -- a digest of its loadable variable names + shapes and its
+                                              feature names, after the same name-by-name comparison with the engine)
 Usage:  python oracle/tools/make_reference_golden.py                 # regenerate both fixtures
         python oracle/tools/make_reference_golden.py --check NAME...  # re-run NAMEs, compare with the committed npz
+        python oracle/tools/make_reference_golden.py --digests        # weight-inventory digests of all configurations
 """
 import dataclasses
 import json
@@ -133,7 +137,77 @@ def check_inventory(name, model, spec):
     return ref, sorted(constants)
 
 
+def inventory_digest(shapes, feature_names):
+    """sha256 over the loadable variables (name + shape, sorted) and the feature names -- tests/test_reference_pin.py
+    computes the same from the engine's ``weight_specs()``."""
+    import hashlib
+    text = "\n".join(f"{k} {tuple(int(d) for d in shapes[k])}" for k in sorted(shapes)) + "|" + ",".join(feature_names)
+    return hashlib.sha256(text.encode()).hexdigest()
+
+
+def engine_specs_all():
+    """Name -> (config, class name, shapes, ignore suffixes, feature names) of every registered configuration, without
+    initialising a single weight."""
+    os.environ.setdefault("TFIMM_ALLOW_NO_GPU", "1")
+    for p in (os.path.join(ROOT, "tensorflow-image-models_amd"), ROOT):
+        sys.path.insert(0, p)
+    import tfimm
+    from tfimm.utils import init as winit
+    fill, winit.initialize = winit.initialize, (lambda specs, mode="keras", seed=0: {})      # inventories only: no values
+    out = {}
+    try:
+        for name in tfimm.list_models():
+            cls, cfg = tfimm.models.model_class(name), tfimm.models.model_config(name)
+            obj = cls(cfg)
+            out[name] = dict(cfg=cfg, cls=cls.__name__, shapes={k: tuple(s.shape) for k, s in obj._specs.items()},
+                             ignore=tuple(cls.keys_to_ignore_on_load), feature_names=list(obj.feature_names))
+    finally:
+        winit.initialize = fill
+    _purge("tfimm")
+    sys.path.remove(os.path.join(ROOT, "tensorflow-image-models_amd"))
+    return out
+
+
+def digests_main():
+    specs = engine_specs_all()
+    tf, tfimm = reference_side()
+    ref_names = set(tfimm.list_models())
+    path = os.path.join(ROOT, "tests", "golden", "reference_weight_digests.json")
+    out = json.load(open(path)) if os.path.exists(path) else {}
+    problems = []
+    for name in sorted(specs, key=lambda n: sum(int(np.prod(s)) for s in specs[n]["shapes"].values())):
+        if name in out:
+            continue
+        if name not in ref_names:
+            problems.append(f"{name}: not registered by the reference")
+            continue
+        t0 = time.time()
+        model = reference_model(tfimm, specs[name])
+        try:
+            ref_shapes, constants = check_inventory(name, model, specs[name])
+        except SystemExit as e:
+            problems.append(str(e))
+            continue
+        if list(model.feature_names) != specs[name]["feature_names"]:
+            problems.append(f"{name}: feature names differ")
+            continue
+        loadable = {k: s for k, s in ref_shapes.items() if k not in constants}
+        out[name] = {"digest": inventory_digest(loadable, list(model.feature_names)), "variables": len(loadable),
+                     "parameters": int(sum(int(np.prod(s)) for s in loadable.values())), "constants": len(constants)}
+        print(f"{name:44s} {len(loadable):5d} variables {out[name]['parameters'] / 1e6:8.1f} M  ({time.time() - t0:.0f} s)", flush=True)
+        del model
+        tf.keras.backend.clear_session()
+        with open(path, "w") as f:          # (written as it goes: the big configurations take minutes each)
+            json.dump(out, f, indent=0, sort_keys=True)
+    for p in problems:
+        print("PROBLEM:", p)
+    missing = sorted(ref_names - set(specs))
+    print(f"{len(out)} digests -> {path}; configurations only the reference registers: {missing}")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--digests":
+        return digests_main()
     check = None
     if len(sys.argv) > 1:
         assert sys.argv[1] == "--check", sys.argv

@@ -42,6 +42,45 @@ def test_weight_inventory_equals_reference(name):
     assert model.weight_names(with_prefix=True)[0] == f"{name}/{next(iter(model._specs))}:0"
 
 
+# ---- every configuration: digests of the reference's loadable variables (names + shapes) and feature names ---------------
+with open(os.path.join(ROOT, "tests", "golden", "reference_weight_digests.json")) as f:
+    DIGESTS = json.load(f)
+
+
+def _engine_inventories():
+    """name -> (shapes, feature names) of every registered configuration, built without initialising any weight."""
+    from tfimm.utils import init as winit
+    fill, winit.initialize = winit.initialize, (lambda specs, mode="keras", seed=0: {})
+    out = {}
+    try:
+        for name in DIGESTS:
+            m = tfimm.models.model_class(name)(tfimm.models.model_config(name))
+            out[name] = ({k: tuple(s.shape) for k, s in m._specs.items()}, list(m.feature_names))
+    finally:
+        winit.initialize = fill
+    return out
+
+
+def test_weight_inventory_digest_of_every_configuration_equals_reference():
+    """oracle/tools/make_reference_golden.py --digests built every configuration the reference registers from the reference's
+    own classes (over the stand-in TensorFlow), compared its variables name by name with the engine's and stored a sha256 of
+    the loadable names + shapes + feature names.  The engine's inventories must still hash to the same values: what
+    ``set_weights`` / timm ingestion key on is the reference's naming for all 196 configurations, not only the 24 whose full
+    inventories are in reference_weights.json."""
+    import hashlib
+    registered = [n for n in tfimm.list_models() if not n.endswith("_test_model") and "_test_model_" not in n]
+    assert sorted(DIGESTS) == sorted(registered), sorted(set(registered) ^ set(DIGESTS))
+    assert len(DIGESTS) == 196
+    bad = []
+    for name, (shapes, feats) in _engine_inventories().items():
+        text = "\n".join(f"{k} {tuple(int(d) for d in shapes[k])}" for k in sorted(shapes)) + "|" + ",".join(feats)
+        ref = DIGESTS[name]
+        if hashlib.sha256(text.encode()).hexdigest() != ref["digest"] or len(shapes) != ref["variables"]:
+            bad.append(name)
+        assert sum(int(np.prod(s)) for s in shapes.values()) == ref["parameters"], name
+    assert not bad, bad
+
+
 def test_inventory_covers_every_family_and_the_scored_models():
     for name in ("vit_base_patch16_224", "resnet50", "swin_base_patch4_window7_224", "efficientnet_b4", "cait_s24_224",
                  "convnext_tiny"):
