@@ -70,8 +70,11 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch every op eagerly instead of replaying a hipGraph")
     ap.add_argument("--extra", default=os.environ.get("TFIMM_BENCH_EXTRA"),
                     help="comma separated further workloads measured after the main one (reported under 'also'); "
-                         f"default: {DEFAULT_EXTRA} on one GPU, vit_base_patch16_224 on several")
+                         f"default: {DEFAULT_EXTRA} on one GPU, vit_base_patch16_224,efficientnet_b4 on several")
     ap.add_argument("--spawn", action="store_true", help="go through the rank launcher even for --gpus 1")
+    ap.add_argument("--backend", default=os.environ.get("TFIMM_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the logits exchange: nccl (= RCCL over xGMI, one rank per GPU) or gloo "
+                         "(host sockets; lets several ranks share one GPU -- how the N > 1 path is exercised on a 1-GPU box)")
     return ap.parse_args()
 
 
@@ -143,6 +146,7 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
     logits = torch.empty(batch, out_t.C, dtype=torch.float32, device="cuda")
     gathered = torch.empty(world * batch, out_t.C, dtype=torch.float32, device="cuda") if dist is not None else None
 
+    host_gather = dist is not None and dist.get_backend() == "gloo"
     use_graph = graph and mb == batch
     captured = None
     if use_graph:
@@ -166,7 +170,13 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
                     run_with_events(plan, x[s:s + nb], events)
                 logits[s:s + nb].copy_(plan.tensor_view(out_t).view(nb, out_t.C))
         if dist is not None:
-            dist.all_gather_into_tensor(gathered, logits)  # the one exchange step: logits of every rank (RCCL)
+            if host_gather:                                # gloo: through pinned host memory (ranks sharing a GPU)
+                lh = logits.cpu()
+                gh = torch.empty(world * batch, out_t.C, dtype=torch.float32)
+                dist.all_gather_into_tensor(gh, lh)
+                gathered.copy_(gh)
+            else:
+                dist.all_gather_into_tensor(gathered, logits)  # the one exchange step: logits of every rank (RCCL)
 
     for _ in range(warmup):
         step()
@@ -369,7 +379,7 @@ def parity_statement(model, xs, ys):
                      "range, so a bf16 forward flips an argmax whenever that gap is inside its error band")
 
 
-def run_workload(name, args, world, rank, dist, steps, warmup, batch=0, micro_batch=0, with_cpu=False):
+def run_workload(name, args, world, rank, dist, steps, warmup, batch=0, micro_batch=0, with_cpu=False, with_parity=False):
     import torch
     wl = WORKLOADS[name]
     batch = batch or wl["batch"]
@@ -379,8 +389,9 @@ def run_workload(name, args, world, rank, dist, steps, warmup, batch=0, micro_ba
     ms = r["ms_per_step"]
     per_rank = [ms]
     if dist is not None:
-        t = torch.tensor([ms], device="cuda")
-        allms = torch.empty(world, device="cuda")
+        dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+        t = torch.tensor([ms], device=dev)
+        allms = torch.empty(world, device=dev)
         dist.all_gather_into_tensor(allms, t)
         per_rank = [round(float(v), 4) for v in allms.tolist()]
         ms = max(per_rank)                                   # max over ranks
@@ -398,6 +409,10 @@ def run_workload(name, args, world, rank, dist, steps, warmup, batch=0, micro_ba
         if with_cpu:
             cpu, xs, ys = cpu_baseline(model, wl["model"])
             out["cpu_baseline"] = cpu
+            out["parity_vs_oracle"] = parity_statement(model, xs, ys)
+        elif with_parity:
+            # N > 1: the CPU baseline is an N = 1 figure, but rank 0 still states parity of what it just ran
+            _, xs, ys = cpu_baseline(model, wl["model"], target_seconds=1.0)
             out["parity_vs_oracle"] = parity_statement(model, xs, ys)
     del r, model
     torch.cuda.empty_cache()
@@ -423,16 +438,23 @@ def main():
         # under a launcher (the driver's torchrun, or spawn_ranks above): one process per GPU, RCCL over xGMI
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())   # ranks may share a GPU
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
 
     main_r = run_workload(args.workload, args, world, rank, dist, args.steps, args.warmup, batch=args.batch,
-                          micro_batch=args.micro_batch, with_cpu=(world == 1 and not args.no_cpu_baseline))
-    extra = args.extra if args.extra is not None else (DEFAULT_EXTRA if world == 1 else "vit_base_patch16_224")
+                          micro_batch=args.micro_batch, with_cpu=(world == 1 and not args.no_cpu_baseline),
+                          with_parity=(world > 1 and not args.no_cpu_baseline))
+    # N > 1: ViT-B/16 (the other half of the headline metric) and EfficientNet-B4 -- BASELINE.json configs[4] is B4 at
+    # 256 per GPU x 8 GPUs = 2048 global, so the driver's plain `bench.py --gpus 8` measures it
+    extra = args.extra if args.extra is not None else (DEFAULT_EXTRA if world == 1 else "vit_base_patch16_224,efficientnet_b4")
     also = {}
     for name in [n for n in extra.split(",") if n and n != args.workload]:
         try:
@@ -451,7 +473,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{m['model']} @{m['input_size']} fwd", "per_gpu_batch": m["per_gpu_batch"],
                        "global_batch": m["global_batch"], "micro_batch": args.micro_batch or m["per_gpu_batch"],
-                       "parallelism": f"dp{world}", "exchange": "RCCL all-gather of fp32 logits" if dist is not None else "none",
+                       "parallelism": f"dp{world}", "exchange": ("none" if dist is None else "RCCL all-gather of fp32 logits" if args.backend == "nccl"
+                                    else "gloo all-gather of fp32 logits (host)"),
                        "ranks": world, "launcher": ("bench.py spawn" if os.environ.get("TFIMM_BENCH_SPAWNED") else
                                                     "external" if launched else "in-process"),
                        "weights": "random-init (synthetic generator, seed 2021)", "launch": m["launch"],

@@ -17,6 +17,7 @@ TFIMM_GEMM_DMA_TILES(TFIMM_DECL)
 TFIMM_GEMM_STREAM_TILES(TFIMM_DECL)
 #undef TFIMM_DECL
 extern "C" const StreamTileCfg tfimm_gemm_stream_tile_7;
+extern "C" const StreamTileCfg tfimm_gemm_stream_tile_9;
 
 namespace {
 
@@ -46,6 +47,7 @@ const StreamTileCfg* stream_tile_table(int i) {
   switch (i) {
     TFIMM_GEMM_STREAM_TILES(TFIMM_CASE)
     case 7: return &tfimm_gemm_stream_tile_7;
+    case 9: return &tfimm_gemm_stream_tile_9;
     default: return nullptr;
   }
 #undef TFIMM_CASE
@@ -110,7 +112,7 @@ int pick_dma_tile(const tfimm_gemm_desc& d) {
 // ceil(tiles / slots) rounds; score = efficiency x useful area x fill of those rounds.
 int pick_stream_tile(const tfimm_gemm_desc& d, const int* occ) {
   if (d.tile_hint > 20 && d.tile_hint <= 20 + TFIMM_GEMM_STREAM_NUM_TILES) return d.tile_hint - 21;
-  static const double eff[TFIMM_GEMM_STREAM_NUM_TILES] = {1.00, 0.90, 0.75, 0.70, 0.55, 0.90, 0.75, 0.0, 0.40};
+  static const double eff[TFIMM_GEMM_STREAM_NUM_TILES] = {1.00, 0.90, 0.75, 0.70, 0.55, 0.90, 0.75, 0.0, 0.40, 0.0};
   const int cus = num_cu();
   int best = 2;
   double best_score = -1.0;
@@ -267,6 +269,7 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       if (!ready[fi][ei]) {
         for (int i = 0; i < TFIMM_GEMM_STREAM_NUM_TILES; ++i) {
           const StreamTileCfg* t = stream_tile_table(i);
+          if (!t->fn[fi][ei]) continue;   // the duo tile has no catch-all flavour (redirected below)
           TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)t->fn[fi][ei], hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_bytes));
           int nb = 0;
           TFIMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)t->fn[fi][ei], t->threads, (size_t)t->lds_bytes));
@@ -278,6 +281,8 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       int occ_f[TFIMM_GEMM_STREAM_NUM_TILES];
       for (int i = 0; i < TFIMM_GEMM_STREAM_NUM_TILES; ++i) occ_f[i] = occ[i][fi];
       int ti = pick_stream_tile(d, occ_f);
+      // the two-workgroups-per-CU tile: vector epilogues only, at least two 32-wide k-tiles; otherwise the 256x128 stream tile
+      if (ti == 9 && (ei == 0 || d.K <= 32 || scale)) ti = 1;
       const StreamTileCfg* t = stream_tile_table(ti);
       if (scale && !t->fn_scale[ei]) {   // the deep-ring tile has no SE-gate flavour
         ti = 0;
@@ -303,7 +308,17 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       const int64_t ntiles = (int64_t)ga.g.tiles_m * ga.g.tiles_n;
       if (ntiles > 0x7fffffffLL) TFIMM_FAIL(TFIMM_EINVAL, "gemm: grid too large");
       ga.n_tiles = (int)ntiles;
-      ga.cin64 = (kmode == K_CONV && (d.Cin % 64) == 0) ? 1 : 0;
+      ga.cin64 = (kmode == K_CONV && (d.Cin % (ti == 9 ? 32 : 64)) == 0) ? 1 : 0;   // whole k-tiles inside one filter tap
+      ga.duo_delay = 0;
+      ga.duo_first = num_cu() / 8;
+      if (ti == 9) {
+        // phase shift of the second workgroup of a CU: about half a tile (a k-tile is 16 MFMAs = 512 cycles of one wave)
+        static const int c1 = getenv("TFIMM_DUO_DELAY_K") ? atoi(getenv("TFIMM_DUO_DELAY_K")) : 256;
+        static const int c0 = getenv("TFIMM_DUO_DELAY_0") ? atoi(getenv("TFIMM_DUO_DELAY_0")) : 2000;
+        const int64_t nk32 = cdiv64(d.K, 32);
+        ga.duo_delay = (int)std::min<int64_t>(nk32 * c1 + c0, 200000);
+        if (c1 == 0 && c0 == 0) ga.duo_delay = 0;
+      }
       ga.cin_magic = ga.kw_magic = 0;
       {
         static const int dbg = getenv("TFIMM_GEMM_DBG") ? atoi(getenv("TFIMM_GEMM_DBG")) : 0;

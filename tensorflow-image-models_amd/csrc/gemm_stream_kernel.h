@@ -52,6 +52,8 @@ struct GemmStreamArgs {
   const float* ln_stats;      // fp32 [M][2]
   const void* ln_c1;          // bf16 [N][2][8] correction fragments (pack.pack_ln_c1)
   unsigned ln_stats_bytes, ln_c1_bytes;
+  // duo kernel (gemm_duo_kernel.h): workgroups with (blockIdx.x >> 3) >= duo_first start duo_delay cycles late
+  int duo_delay, duo_first;
   long long* dbg_ptr; // TFIMM_GEMM_DBG_PTR: s_memtime stamps of workgroup 0 (dbg & 64)
   int dbg;           // TFIMM_GEMM_DBG: bit 64 = record the stamps (tools/gemm_stamps.py)
 };
@@ -152,7 +154,10 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
       const int m = m0 + r;
       const bool ok = valid && m < p.M;
       if (KMODE == K_DENSE) {
-        a_off[j] = ok ? (unsigned)(((size_t)m * p.lda + a_chunk(j) * 8) * 2) : kOobOffset;
+        // TFIMM_GEMM_DBG & 128 (measurement only): every tile fetches the FIRST activation panel -- what the loop does when
+        // the A operand always hits in L2
+        const int msrc = (pa.dbg & 128) ? r : m;
+        a_off[j] = ok ? (unsigned)(((size_t)msrc * p.lda + a_chunk(j) * 8) * 2) : kOobOffset;
         a_iy0[j] = a_ix0[j] = a_pix[j] = 0;
       } else {
         const int mm = ok ? m : 0;
@@ -171,7 +176,8 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
       const int r = (wave * B_INSTR + j) * 8 + lrow;
       const int chunk = lpc ^ ((r >> 1) & 7);
       const int n = n0 + r;
-      b_off[j] = (valid && n < p.N) ? (unsigned)(((size_t)n * p.ldw + chunk * 8) * 2) : kOobOffset;
+      const int nsrc = (pa.dbg & 256) ? r : n;      // measurement only: every tile fetches the first weight panel
+      b_off[j] = (valid && n < p.N) ? (unsigned)(((size_t)nsrc * p.ldw + chunk * 8) * 2) : kOobOffset;
     }
     s_ky = s_kx = s_ci0 = 0;
   };
@@ -733,5 +739,6 @@ struct StreamTileCfg {
   X(6, 256, 64, 4, 1)             \
   X(8, 256, 32, 4, 1)
 // id 7 = the 256x256 deep-ring schedule (gemm_pipe_kernel.h), instantiated on its own; id 8 = narrow outputs
-// (N <= 32 per tile: the 24..48-channel layers of EfficientNet / MobileNet)
-#define TFIMM_GEMM_STREAM_NUM_TILES 9
+// (N <= 32 per tile: the 24..48-channel layers of EfficientNet / MobileNet); id 9 = 256x128 with two co-resident
+// four-wave workgroups per CU (gemm_duo_kernel.h), instantiated on its own
+#define TFIMM_GEMM_STREAM_NUM_TILES 10

@@ -34,8 +34,12 @@ def all_gather_rows(local, batch: int, dist=None):
     if local.shape[0] != mx:
         pad = torch.zeros((mx - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], dim=0)
+    dev = local.device
+    if local.is_cuda and dist.get_backend() == "gloo":
+        local = local.cpu()           # gloo moves bytes over host sockets (ranks may share one GPU); RCCL gathers in HBM
     out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
+    out = out.to(dev)
     if all(s == mx for s in sizes):
         return out
     return torch.cat([out[r * mx:r * mx + sizes[r]] for r in range(world)], dim=0)

@@ -9,15 +9,16 @@
     buffers before the first forward.
 Hints: 0 = library cost model, 11..16 = one-tile-per-workgroup LDS-DMA tiles, 21..26 =
 persistent LDS-DMA tiles (ids: 256x256, 256x128, 128x128, 256x64, 128x64, 128x256; 27 = 256x64 with
-64x64 wave tiles; 28 = 256x256 with the four-stage ring of gemm_pipe_kernel.h; 29 = 256x32 for narrow outputs).
+64x64 wave tiles; 28 = 256x256 with the four-stage ring of gemm_pipe_kernel.h; 29 = 256x32 for narrow outputs;
+30 = 256x128 with two co-resident four-wave workgroups per CU, gemm_duo_kernel.h).
 """
 import json
 import os
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tune.json")
-CANDIDATES = (0, 21, 22, 23, 24, 25, 26, 27, 28, 29, 11, 12, 13, 14, 15, 16)
+CANDIDATES = (0, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 11, 12, 13, 14, 15, 16)
 # a layer with a folded LayerNormalization runs on the persistent tiles only (the library ignores any other hint for it)
-LN_CANDIDATES = (0, 21, 22, 23, 24, 25, 26, 27, 29)
+LN_CANDIDATES = (0, 21, 22, 23, 24, 25, 26, 27, 29, 30)
 TABLE = {}
 _autotune = os.environ.get("TFIMM_AUTOTUNE", "0") == "1"
 
@@ -54,8 +55,25 @@ def candidates_for(d):
     return SCALE_CANDIDATES if getattr(d, "a_scale", None) else CANDIDATES
 
 
+def _parse_remap(spec: str):
+    """``TFIMM_TUNE_REMAP="21:30,28:30"`` -- A/B switch: table entries with the left hint are launched with the right one."""
+    out = {}
+    for item in filter(None, (spec or "").split(",")):
+        a, b = item.split(":")
+        out[int(a)] = int(b)
+    return out
+
+
+_REMAP = _parse_remap(os.environ.get("TFIMM_TUNE_REMAP", ""))
+
+
 def lookup(d) -> int:
-    return TABLE.get(key_of(d), 0)
+    h = TABLE.get(key_of(d), 0)
+    if _REMAP and h in _REMAP:
+        r = _REMAP[h]
+        # hint 30 (two workgroups per CU) has vector epilogues only: the library falls back by itself otherwise
+        return r if r in candidates_for(d) else h
+    return h
 
 
 def load(path: str = _PATH) -> int:

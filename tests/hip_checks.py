@@ -95,15 +95,15 @@ def _gemm_case(M, K, N, *, act="", bias=True, residual=False, act_after_res=Fals
 
 
 # tile hints: 0 auto, 1..6 register-staged tiles, 11..16 LDS-DMA tiles, 21..27 and 29 persistent LDS-DMA tiles,
-# 28 the 256x256 deep-ring schedule
-for _t in list(range(0, 7)) + list(range(11, 17)) + list(range(21, 30)):
+# 28 the 256x256 deep-ring schedule, 30 the 256x128 tile with two co-resident four-wave workgroups per CU (gemm_duo_kernel.h)
+for _t in list(range(0, 7)) + list(range(11, 17)) + list(range(21, 31)):
     CASES[f"gemm_tile{_t:02d}_256x192x320"] = (lambda t=_t: _gemm_case(256, 192, 320, tile=t, seed=1))
     CASES[f"gemm_tile{_t:02d}_ragged_333x200x150_gelu_res"] = (
         lambda t=_t: _gemm_case(333, 200, 150, act="gelu", residual=True, tile=t, seed=2))
     CASES[f"gemm_tile{_t:02d}_600x320x520_relu_after_res_f32"] = (
         lambda t=_t: _gemm_case(600, 320, 520, act="relu", residual=True, act_after_res=True, out_f32=True, tile=t,
                                 seed=3))
-for _t in range(21, 30):
+for _t in range(21, 31):
     # more tiles than resident workgroups: every persistent workgroup walks several tiles (ragged M, N, K)
     CASES[f"gemm_stream_multiround_tile{_t:02d}"] = (
         lambda t=_t: _gemm_case(40000, 200, 520, act="gelu", residual=True, tile=t, seed=50 + t))
@@ -236,7 +236,7 @@ CASES["conv3x3_s2_same_even"] = lambda: _conv_case(2, 20, 20, 16, 24, 3, 2, "sam
 CASES["conv3x3_scalar_cin6"] = lambda: _conv_case(2, 8, 8, 6, 10, 3, 1, 1, act="relu", seed=39)
 CASES["conv3x3_scalar_cin2_s2"] = lambda: _conv_case(3, 9, 9, 2, 4, 3, 2, 1, seed=40)
 CASES["conv1ch_8x8_patch"] = lambda: _conv_case(2, 32, 32, 1, 4, 8, 8, 0, bn=False, seed=41)
-for _t in (1, 2, 3, 4, 5, 6, 11, 12, 13, 14, 15, 16, 21, 22, 23, 24, 25, 26, 27, 28, 29):
+for _t in (1, 2, 3, 4, 5, 6, 11, 12, 13, 14, 15, 16, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30):
     CASES[f"conv3x3_tile{_t:02d}"] = (lambda t=_t: _conv_case(2, 16, 16, 64, 96, 3, 1, 1, act="relu", seed=42, tile=t))
     CASES[f"conv3x3_s2_res_tile{_t:02d}"] = (
         lambda t=_t: _conv_case(3, 15, 13, 40, 72, 3, 2, 1, act="relu", residual=True, seed=43, tile=t))
@@ -290,7 +290,7 @@ CASES["pair_conv4x4_s4_rgb_patch"] = lambda: _conv_case(2, 32, 32, 3, 128, 4, 4,
 CASES["pair_conv3x3_s2_same_rgb_odd"] = lambda: _conv_case(2, 33, 33, 3, 48, 3, 2, "same", act="swish", seed=137, pair=True)
 CASES["pair_conv3x3_s2_same_rgb_380"] = lambda: _conv_case(1, 380, 380, 3, 48, 3, 2, "same", act="swish", seed=140, pair=True)
 CASES["pair_conv1ch_8x8_patch"] = lambda: _conv_case(2, 32, 32, 1, 8, 8, 8, 0, bn=False, seed=138, pair=True)
-for _t in (21, 24, 28):
+for _t in (21, 24, 28, 30):
     CASES[f"conv3x3_stream_multiround_tile{_t:02d}"] = (
         lambda t=_t: _conv_case(32, 56, 56, 64, 64, 3, 1, 1, act="relu", residual=True, seed=70 + t, tile=t))
 # 256x256 persistent tile: deep K (many k-tiles per tile, several tiles per workgroup), K tail, two k-tiles
@@ -303,12 +303,21 @@ CASES["conv3x3_t21_cin128_multiround"] = lambda: _conv_case(24, 28, 28, 128, 256
 CASES["conv3x3_t21_cin40_s2"] = lambda: _conv_case(16, 31, 29, 40, 264, 3, 2, 1, act="relu", seed=95, tile=21)
 CASES["gemm_t29_n24_res_70000x48"] = lambda: _gemm_case(70000, 48, 24, residual=True, tile=29, seed=105)   # narrow-output tile
 CASES["gemm_t24_n144_swish_ragged_tiles"] = lambda: _gemm_case(30000, 24, 144, act="swish", tile=24, seed=106)  # last column tile: one wave fully out of range
-for _t in (21, 28):
+for _t in (21, 28, 30):
     CASES[f"gemm_t{_t}_resmod_remap_19600x200x768"] = (
         lambda t=_t: _gemm_case(19600, 200, 768, residual=True, res_mod=196, remap=(196, 197, 1), tile=t, seed=97))
     CASES[f"conv3x3_t{_t}_cin40_s2_ragged"] = (
         lambda t=_t: _conv_case(16, 31, 29, 40, 264, 3, 2, 1, act="relu", residual=True, seed=98, tile=t))
     CASES[f"gemm_t{_t}_k32_single_ktile"] = (lambda t=_t: _gemm_case(9000, 32, 520, act="relu", tile=t, seed=99))
+# 256x128 two-workgroups-per-CU tile (hint 30): deep K, K tail, two k-tiles, tap stepping at Cin % 32 == 0 and the divide path
+CASES["gemm_t30_deepk_3000x1600x520"] = lambda: _gemm_case(3000, 1600, 520, act="gelu", residual=True, tile=30, seed=191)
+CASES["gemm_t30_two_ktiles_70000x64x512"] = lambda: _gemm_case(70000, 64, 512, tile=30, seed=192)
+CASES["gemm_t30_ktail_5000x200x256"] = lambda: _gemm_case(5000, 200, 256, act="relu", tile=30, seed=193)
+CASES["gemm_t30_vit_fc2_20000x3072x768_res"] = lambda: _gemm_case(20000, 3072, 768, residual=True, tile=30, seed=194)
+CASES["gemm_t30_relu_after_res_90000x128x512"] = lambda: _gemm_case(90000, 128, 512, act="relu", residual=True, act_after_res=True, tile=30, seed=195)
+CASES["conv3x3_t30_cin128_multiround"] = lambda: _conv_case(24, 28, 28, 128, 256, 3, 1, 1, act="relu", residual=True, seed=196, tile=30)
+CASES["conv3x3_t30_cin96_s2"] = lambda: _conv_case(16, 31, 29, 96, 264, 3, 2, 1, act="relu", seed=197, tile=30)
+CASES["conv1x1_t30_s2_cin64"] = lambda: _conv_case(8, 28, 28, 64, 128, 1, 2, 0, seed=198, tile=30)
 CASES["conv3x3_cin128_tapstep"] = lambda: _conv_case(4, 14, 14, 128, 96, 3, 1, 1, act="relu", seed=75)
 CASES["conv3x3_s2_cin192_tapstep"] = lambda: _conv_case(3, 15, 15, 192, 64, 3, 2, 1, seed=76)
 CASES["conv1x1_s2_cin64_stream"] = lambda: _conv_case(2, 28, 28, 64, 128, 1, 2, 0, seed=77, tile=23)
@@ -832,9 +841,11 @@ CASES["ln_gemm_ragged_rows_cols"] = lambda: _ln_gemm_case(333, 192, 200, "gelu",
 CASES["ln_gemm_256x128_tile"] = lambda: _ln_gemm_case(777, 256, 768, "", 345, tile=22)
 CASES["ln_gemm_256x64_tile"] = lambda: _ln_gemm_case(515, 384, 192, "", 346, tile=24, bias=False)
 CASES["ln_gemm_128x256_tile"] = lambda: _ln_gemm_case(400, 1024, 1024, "gelu", 347, tile=26)
-for _t in (21, 22, 23, 24, 25, 26, 27, 29):
+for _t in (21, 22, 23, 24, 25, 26, 27, 29, 30):
     CASES[f"ln_gemm_ragged_tile{_t}"] = (lambda t: lambda: _ln_gemm_case(333, 192, 200, "gelu", 350 + t, tile=t, offset=3.0))(_t)
 CASES["ln_gemm_one_k_tile"] = lambda: _ln_gemm_case(5000, 32, 96, "", 349, offset=1.0)        # nk = 1: the table DMA has to be waited for explicitly
+CASES["ln_gemm_t30_multi_round_gelu"] = lambda: _ln_gemm_case(70000, 768, 384, "gelu", 351, tile=30, offset=1.0)
+CASES["ln_gemm_t30_two_ktiles"] = lambda: _ln_gemm_case(70000, 64, 256, "", 352, tile=30, offset=2.0)
 CASES["ln_gemm_multi_round"] = lambda: _ln_gemm_case(70000, 128, 256, "", 348, offset=1.0)
 
 

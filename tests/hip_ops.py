@@ -84,9 +84,12 @@ def gemm(a, wt, N, K, *, M=None, bias=None, residual=None, out=None, act="", act
     if a_scale is not None:
         d.a_scale = ptr(a_scale)
         d.rows_per_image = rows_per_image
-    d.tile_hint = tile_hint
     if ln_stats is not None:
         d.ln_stats, d.ln_c1 = ptr(ln_stats), ptr(ln_c1)
+    if tile_hint == "table":        # what the engine would launch for this shape (tfimm/engine/gemm_tune.json)
+        from tfimm.engine import tune
+        tile_hint = tune.lookup(d)
+    d.tile_hint = tile_hint
     ffi.check(lib.tfimm_hip_gemm(C.byref(d), stream()), "gemm")
     return out
 
