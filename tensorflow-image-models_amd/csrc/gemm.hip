@@ -269,7 +269,10 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       if (!ready[fi][ei]) {
         for (int i = 0; i < TFIMM_GEMM_STREAM_NUM_TILES; ++i) {
           const StreamTileCfg* t = stream_tile_table(i);
-          if (!t->fn[fi][ei]) continue;   // the duo tile has no catch-all flavour (redirected below)
+          if (!t->fn[fi][ei]) {           // the duo tile has no catch-all flavour (redirected below): two workgroups per CU
+            if (occ[i][fi] == 0) occ[i][fi] = 2;
+            continue;
+          }
           TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)t->fn[fi][ei], hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_bytes));
           int nb = 0;
           TFIMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)t->fn[fi][ei], t->threads, (size_t)t->lds_bytes));

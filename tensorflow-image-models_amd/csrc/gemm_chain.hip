@@ -2,6 +2,7 @@
 // (gemm_chain_kernel.h).
 #include "gemm_chain_kernel.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 using namespace tfimm_gemm;
@@ -51,9 +52,30 @@ extern "C" int tfimm_hip_conv_chain(const tfimm_chain_desc* dp, void* stream) {
     TFIMM_FAIL(TFIMM_EUNSUP, "conv_chain: the shortcut convolution is built for a 64-channel block input and no other residual");
   if (ds && !(d.act1 == TFIMM_ACT_RELU && d.act2 == TFIMM_ACT_RELU))
     TFIMM_FAIL(TFIMM_EUNSUP, "conv_chain: the shortcut-convolution flavour is built with relu activations");
-  if (M > 0x7fffff00LL || x_bytes > 0x7fffff00LL || w1_bytes > 0x7fffff00LL || w2_bytes > 0x7fffff00LL ||
-      out_bytes > 0x7fffff00LL || res_bytes > 0x7fffff00LL)
-    TFIMM_FAIL(TFIMM_EUNSUP, "conv_chain: a tensor exceeds the 2 GiB a buffer descriptor addresses");
+  if (w1_bytes > 0x7fffff00LL || w2_bytes > 0x7fffff00LL)
+    TFIMM_FAIL(TFIMM_EUNSUP, "conv_chain: a weight tensor exceeds the 2 GiB a buffer descriptor addresses");
+  // (TFIMM_CHAIN_LIMIT lowers the threshold: lets a test exercise the chunking on a small batch)
+  static const int64_t limit = getenv("TFIMM_CHAIN_LIMIT") ? std::min<int64_t>(atoll(getenv("TFIMM_CHAIN_LIMIT")), 0x7fffff00LL) : 0x7fffff00LL;
+  if (M > limit || x_bytes > limit || out_bytes > limit || res_bytes > limit) {
+    // An activation tensor beyond the 2 GiB a buffer descriptor addresses (ResNet-50 stage 1 from batch 1338 on: 56 x 56 x 256
+    // bf16 per image): images are independent (stride 1, zero border inside each image), so the batch is run as image
+    // chunks that each fit -- as tfimm_hip_gemm does with the rows of an oversize dense layer.
+    const int64_t per_img = std::max<int64_t>(std::max<int64_t>((int64_t)d.H * d.W * d.Cin * 2, (int64_t)d.OH * d.OW * d.ldc * 2),
+                                              d.residual ? (int64_t)d.OH * d.OW * d.ldr * 2 : 0);
+    const int64_t chunk = limit / per_img;
+    if (chunk < 1 || d.B <= 1) TFIMM_FAIL(TFIMM_EUNSUP, "conv_chain: one image exceeds the 2 GiB a buffer descriptor addresses");
+    for (int64_t b0 = 0; b0 < d.B; b0 += chunk) {
+      tfimm_chain_desc c = d;
+      c.B = (int32_t)std::min<int64_t>(chunk, d.B - b0);
+      c.x = (const char*)d.x + b0 * d.H * d.W * d.Cin * 2;
+      c.out = (char*)d.out + b0 * d.OH * d.OW * d.ldc * 2;
+      if (d.residual) c.residual = (const char*)d.residual + b0 * d.OH * d.OW * d.ldr * 2;
+      if (d.ds_x) c.ds_x = (const char*)d.ds_x + b0 * d.OH * d.OW * d.ds_cin * 2;
+      const int rc = tfimm_hip_conv_chain(&c, stream);
+      if (rc != 0) return rc;
+    }
+    return 0;
+  }
 
   ChainArgs a;
   a.x = (const bf16_t*)d.x; a.w1 = (const bf16_t*)d.w1; a.b1 = d.b1;
