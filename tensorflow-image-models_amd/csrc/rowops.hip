@@ -880,10 +880,10 @@ __global__ void __launch_bounds__(256) dwconv_rows_kernel(const bf16_t* __restri
                 rowtot += tfimm_f32x2{__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)};
               }
             }
-            if (sum_out) {               // (wave-uniform) |row partial| < 32768: v_cvt_i32_f32 saturates beyond
+            if (sum_out) {               // (wave-uniform) 64-bit conversion: a 32-bit one saturates silently at |row partial| = 32768
               rowtot *= 65536.f;
-              tot0 += (long long)__float2int_rn(rowtot.x);
-              tot1 += (long long)__float2int_rn(rowtot.y);
+              tot0 += __float2ll_rn(rowtot.x);
+              tot1 += __float2ll_rn(rowtot.y);
             }
           }
 #pragma unroll

@@ -178,7 +178,13 @@ class Program:
             t = cache.get(ck)
             if t is None:
                 h = c.host
-                if h.dtype == np.uint16:
+                if h is None:
+                    # the host copy went with an earlier upload (another device): copy that device tensor over
+                    src = next((v for k, v in cache.items() if k[1:] == c.key), None)
+                    if src is None:
+                        raise RuntimeError(f"constant {c.key!r}: no host copy and no uploaded copy to take it from")
+                    t = src.to(device)
+                elif h.dtype == np.uint16:
                     t = torch.from_numpy(h.view(np.int16).copy()).to(device)
                 else:
                     t = torch.from_numpy(h.copy()).to(device)
@@ -544,13 +550,17 @@ class Builder:
     # -- normalisation -----------------------------------------------------------------------
     def can_fold_ln(self, x: TRef) -> bool:
         """LayerNormalization over x's channels can be folded into the Dense layers that read it (dense(..., ln=...))."""
-        return x.C % 8 == 0 and x.C <= 2048 and os.environ.get("TFIMM_NO_LN_FOLD", "0") != "1"
+        # the fold lives in the persistent LDS-DMA GEMM family only (tfimm_hip_gemm refuses ln_stats elsewhere)
+        if any(os.environ.get(k, "0") == "1" for k in ("TFIMM_NO_LN_FOLD", "TFIMM_GEMM_NO_STREAM", "TFIMM_GEMM_NO_DMA")):
+            return False
+        return x.C % 8 == 0 and x.C <= 2048
 
     def ln_dense(self, x: TRef, ln_prefix: str, eps: float, kernel: str, bias: Optional[str] = None, *, act="",
                  cite_ln="", cite="") -> TRef:
         """LayerNormalization(ln_prefix) followed by a Dense layer that is its only reader: folded into one GEMM over the raw
         rows + a statistics pass when the row width allows (``can_fold_ln``), the two launches otherwise."""
-        if self.can_fold_ln(x):
+        kshape = self.wget(kernel).shape
+        if self.can_fold_ln(x) and kshape[-1] % 8 == 0:      # the folded epilogue stores whole 16-byte groups
             return self.dense(x, kernel, bias, act=act, ln=(ln_prefix, eps, self.row_stats(x, eps, cite=cite_ln)),
                               cite=(cite_ln + ", " + cite) if cite_ln else cite)
         return self.dense(self.layernorm(x, ln_prefix, eps, cite=cite_ln), kernel, bias, act=act, cite=cite)

@@ -239,6 +239,28 @@ def test_layernorms_with_one_dense_reader_are_folded(monkeypatch):
     monkeypatch.setenv("TFIMM_NO_LN_FOLD", "1")
     kinds2, _ = _kinds("vit_tiny_patch16_224")
     assert "row_stats" not in kinds2 and kinds2.count("layernorm") == 25
+    # the fold exists in the persistent LDS-DMA GEMM family only: switching that family off keeps the LayerNorm launches too
+    monkeypatch.delenv("TFIMM_NO_LN_FOLD")
+    for switch in ("TFIMM_GEMM_NO_STREAM", "TFIMM_GEMM_NO_DMA"):
+        monkeypatch.setenv(switch, "1")
+        kinds3, _ = _kinds("vit_tiny_patch16_224")
+        assert "row_stats" not in kinds3 and kinds3.count("layernorm") == 25, switch
+        monkeypatch.delenv(switch)
+
+
+def test_constants_reach_a_second_device_after_the_host_copies_were_dropped():
+    """Program.upload drops the packed host arrays after the first device upload; a later plan on another device takes the
+    constants from the uploaded copy (devices "cpu" then "meta" here: no GPU needed)"""
+    m = tfimm.create_model("resnet50_mini_test_model")
+    m.set_weights(synthetic_weights(m))
+    p = m.program(64, 64)
+    p.upload("cpu")
+    first = list(p._dev_consts)
+    for c in p.consts:
+        c.host = None                                    # what an upload to a GPU leaves behind
+    p.upload("meta")
+    assert len(p._dev_consts) == len(first)
+    assert all(str(t.device) == "meta" and t.shape == f.shape and t.dtype == f.dtype for t, f in zip(p._dev_consts, first))
 
 
 def test_three_way_bf16_split_is_exact_to_24_bits():
