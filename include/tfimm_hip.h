@@ -485,6 +485,52 @@ TFIMM_API int tfimm_hip_memset_async(void* dst, int value, size_t bytes, void* s
 TFIMM_API int tfimm_hip_bias_act(const void* x, const float* bias, void* y, int64_t rows, int C, int act,
                        void* stream);
 
+/* =======================================================================================
+ * FLOAT32 VERIFICATION PATH (csrc/ref32.hip; selected by TFIMM_PRECISION=fp32, tfimm/engine/precision.py)
+ *
+ * The reference is float32 end to end and pins values at 1e-3 relative to the maximum (tests/test_timm.py:71).  The
+ * entry points below run the SAME layer program as the bf16 kernels above -- same host-side lowering and weight
+ * transformations, minus the cross-layer fusions -- with float32 activations, float32 GEMM weights (Wt[N][ldw] float)
+ * and float32 accumulation, so that the engine's arithmetic can be held to the reference's own bar.  Plain kernels
+ * (one thread / wave per output), 20-50x slower than the product path: a checker, not a fallback -- nothing selects
+ * them unless the caller asks for fp32.  Every signature is the bf16 entry point's with `bf16` tensors replaced by
+ * `float` (descriptor fields keep their meaning; tile_hint / ln_* / bias_log2 are ignored or refused).
+ * tfimm_hip_se_gate and tfimm_hip_eca_gate are float32 already and serve both paths.
+ * ======================================================================================= */
+TFIMM_API int tfimm_hip_ref_gemm(const tfimm_gemm_desc* d, void* stream);   /* TFIMM_A_DENSE and TFIMM_A_CONV (any Cin) */
+/* in_dtype: 0 float32, 1 bf16, 2 uint8 with out = ((float)v / 255 - mean[c]) / std[c] (models/factory.py:165-167);
+ * mean / std: HOST arrays of c_in floats for uint8, NULL otherwise.  out: float32 [n_pixels][c_out], channels >= c_in zero. */
+TFIMM_API int tfimm_hip_ref_cast_input(const void* in, int in_dtype, void* out, int64_t n_pixels, int c_in, int c_out,
+                                       const float* mean, const float* std, void* stream);
+TFIMM_API int tfimm_hip_ref_layernorm(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int d,
+                                      int64_t x_stride, int64_t y_stride, float eps, void* stream);
+TFIMM_API int tfimm_hip_ref_patch_merge_ln(const void* x, void* y, const float* gamma, const float* beta, int B, int H, int W,
+                                           int C, float eps, void* stream);
+TFIMM_API int tfimm_hip_ref_copy_rows(const void* src, void* dst, int B, int src_rows, int dst_rows, int dst_row0, int d,
+                                      void* stream);
+TFIMM_API int tfimm_hip_ref_bcast_rows(const void* src, void* dst, int B, int n_rows, int d, int dst_rows_per_image,
+                                       void* stream);
+TFIMM_API int tfimm_hip_ref_mean_rows(const void* x, void* y, int B, int R, int C, int out_f32, void* stream);
+TFIMM_API int tfimm_hip_ref_scale_channels(const void* x, const float* gate, const void* residual, void* y, int B, int R,
+                                           int C, int act_after, void* stream);
+TFIMM_API int tfimm_hip_ref_maxpool(const void* x, void* y, int B, int H, int W, int C, int k, int stride, int pad, int OH,
+                                    int OW, void* stream);
+TFIMM_API int tfimm_hip_ref_avg_pool(const void* x, void* y, int B, int H, int W, int C, int k, int stride, void* stream);
+TFIMM_API int tfimm_hip_ref_blur_pool(const void* x, void* y, int B, int H, int W, int C, int stride, void* stream);
+/* sum_out must be NULL: on this path the SqueezeExcite mean is a tfimm_hip_ref_mean_rows launch */
+TFIMM_API int tfimm_hip_ref_dwconv(const void* x, const float* w, const float* bias, void* y, void* sum_out, int B, int H,
+                                   int W, int C, int k, int stride, int pad_t, int pad_l, int OH, int OW, int act,
+                                   void* stream);
+TFIMM_API int tfimm_hip_ref_group_norm(const void* x, const float* gamma, const float* beta, const void* residual, void* y,
+                                       void* stats_ws, int B, int rows, int C, int groups, float eps, int act,
+                                       int act_after_res, void* stream);
+TFIMM_API int tfimm_hip_ref_attention(const tfimm_attn_desc* d, void* stream);
+TFIMM_API int tfimm_hip_ref_attention_probs(const void* qkv, void* probs, int B, int n_tokens, int heads, int hd, float scale,
+                                            void* stream);
+TFIMM_API int tfimm_hip_ref_talking_heads_attention(const tfimm_tha_desc* d, void* stream);
+TFIMM_API int tfimm_hip_ref_class_attention(const void* q, const void* kv, void* out, int B, int n_tokens, int heads, int hd,
+                                            int ldq, int ldkv, int ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

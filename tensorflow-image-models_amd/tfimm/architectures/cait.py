@@ -160,10 +160,8 @@ class CaiT(Model):
         eps = _LN_EPS[c.norm_layer]
         D, nh, N = c.embed_dim, c.nb_heads, grid[0] * grid[1]
         scale = (D // nh) ** -0.5
-        from ..engine.pack import to_bf16_bits
-
         x = b.image_input(H, W, c.in_channels)
-        pos_const = b.p.new_const(np.ascontiguousarray(to_bf16_bits(pos[0])), "pos_embed")
+        pos_const = b.act_const(pos[0], "pos_embed")
         x = b.conv(x, "patch_embed/proj/kernel", stride=c.patch_size, padding=0, bias="patch_embed/proj/bias",
                    flatten=True, res_const=pos_const, res_mod=N,
                    cite="layers/transformers.py:164-170 + cait.py:404-413", name="tokens")

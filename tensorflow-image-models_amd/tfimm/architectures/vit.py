@@ -166,7 +166,7 @@ class ViT(Model):
         pos = pos[0]                                               # (N, D)
         x = b.image_input(H, W, c.in_channels)
         # patch conv -> token rows [nt, N), + pos_embed[nt:] in the epilogue
-        pos_const = b.p.new_const(np.ascontiguousarray(_bf16_bits(pos[nt:])), "pos_embed[patches]")
+        pos_const = b.act_const(pos[nt:], "pos_embed[patches]")
         x = b.conv(x, "patch_embed/proj/kernel", stride=c.patch_size, padding=0, bias="patch_embed/proj/bias",
                    flatten=True, remap=(npatch, N, nt), res_const=pos_const, res_mod=npatch,
                    cite="layers/transformers.py:164-170 + vit.py:427-434", name="tokens")
@@ -233,9 +233,6 @@ class ViT(Model):
         return v
 
 
-def _bf16_bits(a):
-    from ..engine.pack import to_bf16_bits
-    return to_bf16_bits(a)
 
 
 # ---------------------------------------------------------------------------------------

@@ -128,6 +128,24 @@ SYMBOLS = {
     "tfimm_hip_eca_gate": (_i, [_vp, _f, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tfimm_hip_grouped_conv3x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "tfimm_hip_bias_act": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
+    # float32 verification path (csrc/ref32.hip): the bf16 signatures with float tensors
+    "tfimm_hip_ref_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
+    "tfimm_hip_ref_cast_input": (_i, [_vp, _i, _vp, _i64, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
+    "tfimm_hip_ref_layernorm": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i64, _i64, _f, _vp]),
+    "tfimm_hip_ref_patch_merge_ln": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "tfimm_hip_ref_copy_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "tfimm_hip_ref_bcast_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "tfimm_hip_ref_mean_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "tfimm_hip_ref_scale_channels": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tfimm_hip_ref_maxpool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "tfimm_hip_ref_avg_pool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "tfimm_hip_ref_blur_pool": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "tfimm_hip_ref_dwconv": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "tfimm_hip_ref_group_norm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "tfimm_hip_ref_attention": (_i, [C.POINTER(AttnDesc), _vp]),
+    "tfimm_hip_ref_attention_probs": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "tfimm_hip_ref_talking_heads_attention": (_i, [C.POINTER(ThaDesc), _vp]),
+    "tfimm_hip_ref_class_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tfimm_hip_memset_async": (_i, [_vp, _i, C.c_size_t, _vp]),
 }
 

@@ -19,7 +19,7 @@ from typing import Callable, Dict, List, Optional, Tuple
 import numpy as np
 
 from ..utils.etc import same_padding
-from . import pack, tune
+from . import pack, precision, tune
 
 
 # ---------------------------------------------------------------------------------------
@@ -72,6 +72,9 @@ class Op:
 
 class Program:
     def __init__(self):
+        # "bf16": the product path; "fp32": the verification path (engine/precision.py) -- every activation tensor is
+        # float32 and the plan binds the tfimm_hip_ref_* kernels
+        self.precision = precision.get()
         self.tensors: List[TRef] = []
         self.consts: List[Const] = []
         self.ops: List[Op] = []
@@ -84,6 +87,8 @@ class Program:
 
     # -- construction helpers -------------------------------------------------------------
     def new_tensor(self, rows, C, H=0, W=0, dtype="bf16", name="") -> TRef:
+        if dtype == "bf16" and self.precision == "fp32":
+            dtype = "f32"
         t = TRef(len(self.tensors), int(rows), int(C), int(H), int(W), dtype, False, name)
         self.tensors.append(t)
         return t
@@ -206,6 +211,7 @@ class Builder:
         self.w = weights
         self._orig_w = weights
         self.p = Program()
+        self.fp32 = self.p.precision == "fp32"      # verification path: no cross-layer fusion, unrounded weights
 
     # -- weights ---------------------------------------------------------------------------
     def wget(self, name: str) -> np.ndarray:
@@ -221,6 +227,12 @@ class Builder:
         self.w[name] = np.asarray(value, dtype=np.float32)
         return name
 
+    def act_const(self, value: np.ndarray, name: str) -> int:
+        """A constant in ACTIVATION storage (e.g. position embeddings added as a GEMM residual): bf16 bits on the product
+        path, float32 on the verification path."""
+        v = np.ascontiguousarray(value, dtype=np.float32)
+        return self.p.new_const(v if self.fp32 else pack.to_bf16_bits(v), name)
+
     def bn(self, prefix: str, eps: float):
         """Folded inference BatchNorm -> (scale, shift).  Keras BN: layers/factory.py:22-37."""
         return pack.bn_scale_shift(self.wget(prefix + "/gamma"), self.wget(prefix + "/beta"),
@@ -231,7 +243,7 @@ class Builder:
     def image_input(self, H: int, W: int, cin: int) -> TRef:
         """Caller's NHWC float image -> bf16 NHWC with padded channels (tfimm_hip_cast_input)."""
         p = self.p
-        cpad = pack.pad_channels(cin)
+        cpad = cin if self.fp32 else pack.pad_channels(cin)
         raw = p.new_tensor(H * W, cin, H, W, dtype="raw", name="input")
         raw.keep = True
         p.input = raw
@@ -296,7 +308,8 @@ class Builder:
         # cast (tfimm_hip_cast_input_pad) and the conv runs on the pixel-PAIR view [Hp][Wp/2][8] of the
         # padded 4-channel image -- no bounds checks, Cin % 8 == 0, so the operand tiles go by LDS-DMA.
         pair_view = (x.C == 4 and getattr(self, "_cast_out", None) == x.id and stride % 2 == 0 and a_scale is None
-                     and self._cast_op.attrs["pad"] == (0, 0, 0, 0) and not self._cast_op.attrs.get("used"))
+                     and self._cast_op.attrs["pad"] == (0, 0, 0, 0) and not self._cast_op.attrs.get("used")
+                     and not self.fp32)
         if pair_view:
             kwp = (kw + 1) // 2 * 2
             wp = max(x.W + pl, (OW - 1) * stride + kwp)
@@ -318,11 +331,12 @@ class Builder:
             attrs.update(mode=1, K=kk, H=hp, W=wp // 2, Cin=8, KH=kh, KW=kwp // 2, stride=stride, stride_w=stride // 2,
                          pad_t=0, pad_l=0, OH=OH, OW=OW)
         elif pointwise:
-            wt, bvec = pack.pack_dense(k.reshape(cin, cout) * (1.0 if scale is None else scale.reshape(1, cout)), shift)
+            wt, bvec = pack.pack_dense(k.reshape(cin, cout) * (1.0 if scale is None else scale.reshape(1, cout)), shift,
+                                       fp32=self.fp32)
             attrs.update(mode=0, K=cin, lda=x.C, a_rows_per_image=x.rows)
         else:
             assert a_scale is None
-            wt, bvec, kk, mode = pack.pack_conv(k, scale, shift, x.C)
+            wt, bvec, kk, mode = pack.pack_conv(k, scale, shift, x.C, fp32=self.fp32)
             attrs.update(mode=mode, K=kk, H=x.H, W=x.W, Cin=x.C, KH=kh, KW=kw, stride=stride,
                          pad_t=pt, pad_l=pl, OH=OH, OW=OW)
         consts["wt"] = p.new_const(wt, kernel)
@@ -360,7 +374,8 @@ class Builder:
         n2 = k2.shape[3]
         # what tfimm_hip_conv_chain is built for: 3x3 / stride 1 / pad 1 over 64 -> 64 channels, rows of at most 63 pixels
         if (x.C != cin or (kh, kw, cin, c1) != (3, 3, 64, 64) or stride != 1 or int(padding) != 1 or x.W > 63
-                or n2 not in (256, 512) or k2.shape[:3] != (1, 1, c1) or os.environ.get("TFIMM_NO_CHAIN", "0") == "1"):
+                or n2 not in (256, 512) or k2.shape[:3] != (1, 1, c1) or os.environ.get("TFIMM_NO_CHAIN", "0") == "1"
+                or self.fp32):
             return None
         if shortcut_conv is not None:
             x0, kds, _ = shortcut_conv
@@ -409,7 +424,7 @@ class Builder:
         k = self.wget(kernel)
         kh, kw, w, c = k.shape
         if ((kh, kw) != (3, 3) or c != w * groups or x.C != c or w > 32 or 32 % w or c % 32 or stride not in (1, 2)
-                or os.environ.get("TFIMM_NO_GROUPED", "0") == "1"):
+                or os.environ.get("TFIMM_NO_GROUPED", "0") == "1" or self.fp32):
             return None
         scale = shift = None
         if bn is not None:
@@ -432,7 +447,7 @@ class Builder:
         p = self.p
         k = self.wget(kernel)
         kh, kw, w, c = k.shape
-        if c % groups or x.C != w * groups or w % 8 or (c // groups) % 8:
+        if c % groups or x.C != w * groups or ((w % 8 or (c // groups) % 8) and not self.fp32):
             return None
         wo = c // groups
         pad = int(padding)
@@ -445,13 +460,13 @@ class Builder:
         for g in range(groups):
             sl = slice(g * wo, (g + 1) * wo)
             wt, bvec, kk, mode = pack.pack_conv(k[..., sl], None if scale is None else scale[sl],
-                                                None if shift is None else shift[sl], w)
+                                                None if shift is None else shift[sl], w, fp32=self.fp32)
             consts = {"wt": p.new_const(wt, f"{kernel}:g{g}")}
             if bvec is not None:
                 consts["bias"] = p.new_const(bvec, f"{kernel}:g{g}:bias")
             p.add("gemm", [x], out, consts, cite=cite, M=OH * OW, N=wo, K=kk, K_true=kk, mode=mode, H=x.H, W=x.W, Cin=w,
                   KH=kh, KW=kw, stride=stride, pad_t=pad, pad_l=pad, OH=OH, OW=OW, ldw=wt.shape[1], act=act,
-                  act_after_res=False, out_f32=0, pix_pitch=x.C, a_byte_offset=g * w * 2, out_col=g * wo, ldc=c)
+                  act_after_res=False, out_f32=0, pix_pitch=x.C, a_byte_offset=g * w * x.itemsize, out_col=g * wo, ldc=c)
         return out
 
     def dense(self, x: TRef, kernel: str, bias: Optional[str] = None, *, act="",
@@ -499,7 +514,7 @@ class Builder:
             shift = bet @ k.astype(np.float64)                     # beta . W (+ b): what LN's beta contributes to every row
             bvec_in = (shift if bvec_in is None else shift + bvec_in).astype(np.float32)
             k = (k.astype(np.float64) * gam.reshape(kin, 1)).astype(np.float32)
-        wt, bvec = pack.pack_dense(k, bvec_in)
+        wt, bvec = pack.pack_dense(k, bvec_in, fp32=self.fp32)
         rows = x.rows
         attrs = dict(M=rows, N=kout, K=kin, K_true=kin, mode=0, lda=x.C, act=act, act_after_res=False,
                      out_f32=1 if out_f32 else 0, res_mod=0, remap=None, ldw=wt.shape[1],
@@ -507,10 +522,10 @@ class Builder:
         if row_select is not None:
             first, count = row_select
             assert count == 1, "row_select takes one row per image"
-            attrs.update(M=1, a_byte_offset=first * x.C * 2, lda=x.rows * x.C)
+            attrs.update(M=1, a_byte_offset=first * x.C * x.itemsize, lda=x.rows * x.C)
             rows = 1
         if in_cols is not None:
-            attrs["a_byte_offset"] = attrs.get("a_byte_offset", 0) + in_cols[0] * 2
+            attrs["a_byte_offset"] = attrs.get("a_byte_offset", 0) + in_cols[0] * x.itemsize
         if out is None:
             sp = (x.H, x.W) if (row_select is None and x.H * x.W == rows) else (0, 0)   # Dense keeps the spatial grid
             out = p.new_tensor(rows, kout, sp[0], sp[1], dtype="f32" if out_f32 else "bf16", name=name or kernel)
@@ -538,7 +553,7 @@ class Builder:
             if residual_row is not None:
                 assert rows == 1 and residual_row < residual.rows
                 attrs["ldr"] = residual.rows * residual.C
-                attrs["res_byte_offset"] = residual_row * residual.C * 2
+                attrs["res_byte_offset"] = residual_row * residual.C * residual.itemsize
             else:
                 assert residual.rows == rows
         p.add("gemm", ins, out, consts, cite=cite, **attrs)
@@ -553,7 +568,7 @@ class Builder:
         # the fold lives in the persistent LDS-DMA GEMM family only (tfimm_hip_gemm refuses ln_stats elsewhere)
         if any(os.environ.get(k, "0") == "1" for k in ("TFIMM_NO_LN_FOLD", "TFIMM_GEMM_NO_STREAM", "TFIMM_GEMM_NO_DMA")):
             return False
-        return x.C % 8 == 0 and x.C <= 2048
+        return x.C % 8 == 0 and x.C <= 2048 and not self.fp32
 
     def ln_dense(self, x: TRef, ln_prefix: str, eps: float, kernel: str, bias: Optional[str] = None, *, act="",
                  cite_ln="", cite="") -> TRef:
@@ -591,9 +606,9 @@ class Builder:
         else:
             first, count = row_select
             assert count == 1
-            attrs = dict(rows=1, x_stride=x.rows * x.C, x_byte_offset=first * x.C * 2)
+            attrs = dict(rows=1, x_stride=x.rows * x.C, x_byte_offset=first * x.C * x.itemsize)
         p.add("layernorm", [x], out, consts, cite=cite, eps=float(eps), d=x.C, y_stride=out.C,
-              y_byte_offset=out_col * 2, **attrs)
+              y_byte_offset=out_col * out.itemsize, **attrs)
         return out
 
     # -- attention ---------------------------------------------------------------------------
@@ -671,7 +686,7 @@ class Builder:
     def token_rows(self, dst: TRef, rows_host: np.ndarray, cite="") -> None:
         """Write constant rows (class / distillation token + their pos_embed) into the first
         rows of every image of ``dst`` (tfimm_hip_bcast_rows)."""
-        bits = pack.to_bf16_bits(rows_host)
+        bits = np.ascontiguousarray(rows_host, dtype=np.float32) if self.fp32 else pack.to_bf16_bits(rows_host)
         cid = self.p.new_const(bits, "token_rows")
         self.p.add("bcast_rows", [dst], dst, {"src": cid}, cite=cite, n_rows=rows_host.shape[0],
                    d=rows_host.shape[1], dst_rows=dst.rows)
@@ -704,6 +719,13 @@ class Builder:
             consts["bias"] = p.new_const(bvec, kernel + ":bias")
         sums = None
         ins = [x]
+        if squeeze and self.fp32:
+            # verification path: the squeeze is its own launch (the mean of the float32 output, efficientnet_blocks.py:242)
+            p.add("dwconv", ins, out, consts, cite=cite, H=x.H, W=x.W, C=c, k=kh, stride=stride, pad_t=pt, pad_l=pl, OH=OH,
+                  OW=OW, act=act, sums=None)
+            mean = self.mean_rows(out, out_f32=True, cite="efficientnet_blocks.py:242")
+            mean.is_mean = True
+            return out, mean
         if squeeze:
             sums = p.new_tensor(1, 2 * c, dtype="f32", name=(name or kernel) + ":sums")     # int64 fixed point per channel
         p.add("dwconv", ins, out, consts, cite=cite, extra_outputs=[sums] if sums is not None else [],
@@ -722,7 +744,8 @@ class Builder:
         cin, c = k1.shape[2], k1.shape[3]
         kh, kw = kd.shape[:2]
         if (k1.shape[:2] != (1, 1) or x.C != cin or cin % 8 or cin > 32 or c % 2 or kd.shape[2:] != (c, 1) or kh != kw
-                or (kh, stride) not in ((3, 1), (3, 2), (5, 2)) or os.environ.get("TFIMM_NO_MBCONV_FUSION", "0") == "1"):
+                or (kh, stride) not in ((3, 1), (3, 2), (5, 2)) or os.environ.get("TFIMM_NO_MBCONV_FUSION", "0") == "1"
+                or self.fp32):
             return None
         if padding == "same":
             OH, pt, _ = same_padding(x.H, kh, stride)
@@ -765,7 +788,7 @@ class Builder:
         kh, kw, cin, c = ks.shape
         if (x.C != 4 or getattr(self, "_cast_out", None) != x.id or self._cast_op.attrs["pad"] != (0, 0, 0, 0)
                 or self._cast_op.attrs.get("used") or (kh, kw) != (3, 3) or stride != 2 or cin > 4 or c % 2
-                or kd.shape != (3, 3, c, 1) or os.environ.get("TFIMM_NO_MBCONV_FUSION", "0") == "1"):
+                or kd.shape != (3, 3, c, 1) or os.environ.get("TFIMM_NO_MBCONV_FUSION", "0") == "1" or self.fp32):
             return None
         if padding == "same":
             SH, pt, _ = same_padding(x.H, 3, 2)
@@ -819,6 +842,8 @@ class Builder:
         # sums straight from a depthwise producer are int64 fixed point (2 floats of storage per channel); means are fp32
         fixed = sums.C == 2 * c
         assert fixed or sums.C == c
+        if getattr(sums, "is_mean", False):      # fp32 path: dwconv(squeeze=True) already handed back the mean
+            count = 1
         p.add("se_gate", [sums], gate, consts, cite=cite, C=c, rd=rd, inv_count=1.0 / count, act=act,
               gate_act=gate_act, sums_fixed=1 if fixed else 0)
         return gate
@@ -913,7 +938,9 @@ class Plan:
         self._gemm_call_index = []
         self._tune_times = {}          # shape key -> {hint: ms} of the last isolated autotune
         self._build()
-        if device != "cpu" and tune.autotune_enabled():
+        if prog.precision == "fp32":
+            self._bind_fp32()
+        elif device != "cpu" and tune.autotune_enabled():
             self.autotune()
 
     # pointers ----------------------------------------------------------------------------------
@@ -1150,6 +1177,32 @@ class Plan:
             else:
                 raise NotImplementedError(k)
 
+    # kernels that are float32 on both paths
+    _FP32_SHARED = ("tfimm_hip_se_gate", "tfimm_hip_eca_gate")
+
+    def _bind_fp32(self):
+        """Verification path (engine/precision.py): every call of the list goes to the float32 kernel of the same name
+        (csrc/ref32.hip: tfimm_hip_ref_*, same arguments); ops that only exist as bf16 fusions must not be in the program."""
+        lib = self.ffi.lib
+        calls = []
+        for fn, args in self.calls:
+            if fn == "memset":
+                calls.append((fn, args))
+                continue
+            name = fn.__name__
+            if name in self._FP32_SHARED:
+                calls.append((fn, args))
+                continue
+            ref = getattr(lib, name.replace("tfimm_hip_", "tfimm_hip_ref_", 1), None)
+            if ref is None or not name.startswith("tfimm_hip_"):
+                raise NotImplementedError(f"{name} has no float32 counterpart: the fp32 lowering must not emit it")
+            calls.append((ref, args))
+        self.calls = calls
+        out, n_pixels, c_in, c_out = self._input_patch[1:5]
+        self._input_call = (lib.tfimm_hip_ref_cast_input, (out, n_pixels, c_in, c_out))
+        self._input_call_u8 = None
+        self._stem_raw = None
+
     def autotune(self, iters: int = 3, verbose: bool = False) -> int:
         """Time every GEMM launch of this plan with each tile shape of the LDS-DMA families (on the
         plan's own buffers) and keep the fastest (tfimm_gemm_desc.tile_hint).  Results are cached
@@ -1257,7 +1310,10 @@ class Plan:
             if fn == "memset":
                 assert len(args) == 2
                 continue
-            if args is None:  # cast_input: patched per call
+            if args is None and self.prog.precision == "fp32":
+                args = (0, 0) + tuple(self._input_call[1]) + (None, None)
+                fn = self._input_call[0]
+            elif args is None:  # cast_input: patched per call
                 args = (0, 0) + tuple(self._input_call[1])
                 c_in = self._input_patch[3]
                 u8_fn, u8_args = self._input_call_u8
@@ -1284,6 +1340,13 @@ class Plan:
         c_in = self._input_patch[3]
         if (x_dev.dtype == torch.uint8) != (norm is not None):
             raise TypeError("uint8 input needs norm=(mean, std); float input must not pass it")
+        if self.prog.precision == "fp32":
+            mean = std = None
+            if norm is not None:
+                mean = (C.c_float * c_in)(*[float(v) for v in norm[0]])
+                std = (C.c_float * c_in)(*[float(v) for v in norm[1]])
+            in_dtype = 2 if norm is not None else (1 if x_dev.dtype == torch.bfloat16 else 0)
+            return self._input_call[0](x_dev.data_ptr(), in_dtype, *self._input_call[1], mean, std, st)
         if self._stem_raw is not None:
             d, padded_ptr, ih, iw, pad_t, pad_l = self._stem_raw
             raw = (norm is None and not force_convert and x_dev.dtype in (torch.bfloat16, torch.float32)

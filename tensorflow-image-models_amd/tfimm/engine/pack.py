@@ -42,23 +42,28 @@ def pad_channels(cin: int) -> int:
     return 4 if cin <= 4 else ceil_to(cin, 8)
 
 
-def pack_matrix(w_nk: np.ndarray) -> np.ndarray:
-    """[N][K] fp32 -> [N][ceil64(K)] bf16 bits, zero padded."""
+def pack_matrix(w_nk: np.ndarray, fp32: bool = False) -> np.ndarray:
+    """[N][K] fp32 -> [N][ceil64(K)] bf16 bits, zero padded (``fp32``: the same layout in float32 -- the verification
+    path of engine/precision.py keeps the weights unrounded)."""
     n, k = w_nk.shape
+    if fp32:
+        out32 = np.zeros((n, ceil_to(k, 64)), dtype=np.float32)
+        out32[:, :k] = w_nk
+        return out32
     out = np.zeros((n, ceil_to(k, 64)), dtype=np.uint16)  # 64: one whole LDS-DMA K-tile
     out[:, :k] = to_bf16_bits(w_nk)
     return out
 
 
-def pack_dense(kernel: np.ndarray, bias: Optional[np.ndarray]):
+def pack_dense(kernel: np.ndarray, bias: Optional[np.ndarray], fp32: bool = False):
     """Keras Dense kernel (in, out) -> Wt[out][in]."""
-    wt = pack_matrix(np.ascontiguousarray(kernel.T))
+    wt = pack_matrix(np.ascontiguousarray(kernel.T), fp32)
     b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
     return wt, b
 
 
 def pack_conv(kernel: np.ndarray, scale: Optional[np.ndarray], shift: Optional[np.ndarray],
-              cin_stored: int):
+              cin_stored: int, fp32: bool = False):
     """HWIO conv kernel -> (Wt, bias, K, mode).
 
     ``cin_stored`` is the channel count of the activation tensor in HBM (4 for padded RGB).
@@ -68,7 +73,7 @@ def pack_conv(kernel: np.ndarray, scale: Optional[np.ndarray], shift: Optional[n
     k = kernel.astype(np.float32)
     if scale is not None:
         k = k * scale.reshape(1, 1, 1, cout)
-    if cin_stored == 4:
+    if cin_stored == 4 and not fp32:
         assert cin <= 4
         kwp = (kw + 1) // 2 * 2
         kp = np.zeros((kh, kwp, 4, cout), dtype=np.float32)
@@ -81,7 +86,7 @@ def pack_conv(kernel: np.ndarray, scale: Optional[np.ndarray], shift: Optional[n
         else:
             kp = k
         mode, kk = 1, kh * kw * cin_stored
-    wt = pack_matrix(np.ascontiguousarray(kp.reshape(kk, cout).T))
+    wt = pack_matrix(np.ascontiguousarray(kp.reshape(kk, cout).T), fp32)
     b = None if shift is None else np.ascontiguousarray(shift, dtype=np.float32)
     return wt, b, kk, mode
 

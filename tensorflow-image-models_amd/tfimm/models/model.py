@@ -17,6 +17,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
+from ..engine import precision
 from ..engine.graph import Builder, Program
 from ..utils import init as winit
 
@@ -174,7 +175,7 @@ class Model:
     def program(self, H: Optional[int] = None, W: Optional[int] = None, want_features=False) -> Program:
         H = H or self.cfg.input_size[0]
         W = W or self.cfg.input_size[1]
-        key = (H, W, bool(want_features))
+        key = (H, W, bool(want_features), precision.get())
         if key not in self._programs:
             b = Builder(self._weights)
             b.p.const_cache = self._const_cache
@@ -223,7 +224,7 @@ class Model:
         results: Dict[str, list] = {k: [] for k in prog.outputs}
         for start in range(0, B, mb):
             nb = min(mb, B - start)
-            key = (H, W, bool(want_features), nb)
+            key = (H, W, bool(want_features), nb, precision.get())
             plan = self._plans.get(key)
             if plan is None:
                 plan = prog.make_plan(nb)

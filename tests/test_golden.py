@@ -54,9 +54,21 @@ def test_baseline_config0_vit_tiny_b1_cpu():
     assert mc.rel_err(oracle.forward(model.cfg, w, x), GOLD["vit_tiny_patch16_224/logits"]) <= TOL_RESTATEMENT
 
 
-# 4-channel LayerNorms (the reference's own mini hyper-parameters): one bf16 ulp of the residual stream moves a
-# value normalised over 4 channels by percent -- twice the bar, no top-1 requirement (see test_gpu_models.py)
-_LOOSE = ("vit_test_model", "deit_test_model", "cait_test_model", "convnext_test_model", "swin_test_model")
+# Per-model bf16 bars: 2 x the error observed on an MI355X (tests/golden/bf16_bars.json, tools/measure_bf16_bars.py).  The
+# forward is bit-reproducible, so a kernel change that moves a model's error past twice today's figure is a regression to look
+# at, not noise.  That the arithmetic is the reference's -- and not just something inside a bf16 band -- is established by
+# the float32 path against the same vectors at 1e-3 (tests/test_gpu_fp32.py).
+import json  # noqa: E402
+
+BARS = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_bars.json")))["models"]
+
+
+def test_every_golden_model_has_a_bf16_bar_and_none_is_looser_than_the_global_bar():
+    assert sorted(BARS) == MODELS
+    for name, b in BARS.items():
+        assert 0 < b["logits_bar"] <= 2.1 * b["observed_logits"], name      # 2 x observed, rounded up to two digits
+        # the 4-channel minis (vit_test_model, cait_test_model: LayerNorm over 4 values) are the only ones past 5e-2
+        assert b["logits_bar"] <= mc.TOL_LOGITS or name in ("vit_test_model", "cait_test_model"), name
 
 
 @pytest.mark.gpu
@@ -66,9 +78,8 @@ def test_engine_matches_reference_code_path(name):
     model.set_weights(w)
     ref = GOLD[f"{name}/logits"]
     got = model(x).numpy().reshape(ref.shape)
-    tol = 2 * mc.TOL_LOGITS if name in _LOOSE else mc.TOL_LOGITS
-    assert mc.rel_err(got, ref) <= tol
-    if name not in _LOOSE:
+    assert mc.rel_err(got, ref) <= BARS[name]["logits_bar"]
+    if BARS[name]["top1"]:
         assert (got.argmax(-1) == ref.argmax(-1)).all()
 
 
@@ -82,7 +93,7 @@ def test_engine_features_match_reference_code_path(name):
     _, feats = model(x, return_features=True)
     frozen = _features(name)
     assert list(feats.keys()) == frozen
-    tol = 2 * mc.TOL_LOGITS if name in _LOOSE else mc.TOL_LOGITS
+    tol = BARS[name]["features_bar"]
     for k in frozen:
         ref = GOLD[f"{name}/feat/{k}"]
         assert mc.rel_err(feats[k].numpy().reshape(ref.shape), ref) <= tol, k

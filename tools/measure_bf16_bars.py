@@ -1,0 +1,63 @@
+"""Observed error of the bf16 product path against the reference-code goldens, per model and per feature:
+writes gpurun_out/bf16_observed.json.  tests/golden/bf16_bars.json (the bars the GPU tests hold the engine to) is 2x these
+numbers (tools/measure_bf16_bars.py --write-bars, rounded up to two significant digits)."""
+import json
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tensorflow-image-models_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np
+
+import model_checks as mc
+import test_architectures  # noqa: F401
+import tfimm
+from tfimm.utils.init import synthetic_weights
+
+GOLD = np.load(os.path.join(ROOT, "tests", "golden", "forward_golden.npz"))
+MODELS = sorted({k.split("/")[0] for k in GOLD.files})
+
+
+def ceil2(v):
+    if v <= 0:
+        return 0.0
+    e = math.floor(math.log10(v)) - 1
+    return math.ceil(v / 10 ** e) * 10 ** e
+
+
+def main():
+    obs = {}
+    for name in MODELS:
+        model = tfimm.create_model(name)
+        model.set_weights(synthetic_weights(model, 2021))
+        ref = GOLD[f"{name}/logits"]
+        x = mc.make_input(model.cfg, ref.shape[0])
+        pre = f"{name}/feat/"
+        frozen = [k[len(pre):] for k in GOLD.files if k.startswith(pre)]
+        if frozen:
+            got, feats = model(x, return_features=True)
+        else:
+            got, feats = model(x), {}
+        g = got.numpy().reshape(ref.shape)
+        srt = np.sort(ref.reshape(-1, ref.shape[-1]), -1)
+        row_err = np.abs(g - ref).reshape(-1, ref.shape[-1]).max(-1)
+        margin = srt[:, -1] - srt[:, -2]
+        agree = g.reshape(-1, ref.shape[-1]).argmax(-1) == ref.reshape(-1, ref.shape[-1]).argmax(-1)
+        obs[name] = {"logits": mc.rel_err(g, ref), "top1_agree": float(agree.mean()),
+                     "min_margin_over_row_err": float((margin / np.maximum(row_err, 1e-30)).min()),
+                     "features": {k: mc.rel_err(feats[k].numpy().reshape(GOLD[pre + k].shape), GOLD[pre + k]) for k in frozen}}
+        print(name, f"{obs[name]['logits']:.3e}", obs[name]["top1_agree"], f"{obs[name]['min_margin_over_row_err']:.2f}",
+              f"max feat {max(obs[name]['features'].values(), default=0):.3e}", flush=True)
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(obs, open(os.path.join(out, "bf16_observed.json"), "w"), indent=1, sort_keys=True)
+    if "--write-bars" in sys.argv:
+        bars = {n: {"logits": ceil2(2 * o["logits"]), "features": ceil2(2 * max(o["features"].values(), default=0.0)),
+                    "top1": bool(o["top1_agree"] == 1.0)} for n, o in obs.items()}
+        json.dump(bars, open(os.path.join(out, "bf16_bars.json"), "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
