@@ -66,7 +66,7 @@ BARS = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "
 def test_every_golden_model_has_a_bf16_bar_and_none_is_looser_than_the_global_bar():
     assert sorted(BARS) == MODELS
     for name, b in BARS.items():
-        assert 0 < b["logits_bar"] <= 2.1 * b["observed_logits"], name      # 2 x observed, rounded up to two digits
+        assert 0 < b["logits_bar"] <= 2.2 * b["observed_logits"], name      # 2 x observed, rounded up to two digits
         # the 4-channel minis (vit_test_model, cait_test_model: LayerNorm over 4 values) are the only ones past 5e-2
         assert b["logits_bar"] <= mc.TOL_LOGITS or name in ("vit_test_model", "cait_test_model"), name
 
