@@ -119,3 +119,92 @@ def test_bf16_bits_round_to_nearest_even_like_torch():
     ours = pack.bf16_bits_to_f32(pack.to_bf16_bits(a))
     ref = torch.from_numpy(a).to(torch.bfloat16).float().numpy()
     assert np.array_equal(ours, ref)
+
+
+# ---- known answers for the ops round 2 left to "engine == oracle" (two implementations by one author) ---------------------
+def _keys(t, A=-0.5):
+    """Keys cubic convolution kernel (the published definition behind tf.image.resize(method="bicubic"))."""
+    t = abs(t)
+    if t < 1:
+        return ((A + 2) * t - (A + 3)) * t * t + 1
+    if t < 2:
+        return ((A * t - 5 * A) * t + 8 * A) * t - 4 * A
+    return 0.0
+
+
+def _bicubic_1d_analytic(v, n_out):
+    """half-pixel centres, taps outside the image weigh 0, the rest renormalised -- from the kernel's definition, exact offsets"""
+    n_in = len(v)
+    out = []
+    for o in range(n_out):
+        loc = (o + 0.5) * n_in / n_out - 0.5
+        base = math.floor(loc)
+        taps = [(i, _keys(loc - i)) for i in range(base - 1, base + 3) if 0 <= i < n_in]
+        tot = sum(w for _, w in taps)
+        out.append(sum(v[i] * w for i, w in taps) / tot)
+    return np.array(out)
+
+
+def test_resize_bicubic_hand_computed_4_to_8_and_5_to_3():
+    # 4 -> 8: source offsets are exactly 0.25 / 0.75, Keys weights 0.8671875, 0.2265625, -0.0703125, -0.0234375 (sum 1)
+    assert abs(_keys(0.25) - 0.8671875) < 1e-12 and abs(_keys(0.75) - 0.2265625) < 1e-12
+    assert abs(_keys(1.25) + 0.0703125) < 1e-12 and abs(_keys(1.75) + 0.0234375) < 1e-12
+    v = np.array([1.0, 2.0, 3.0, 4.0], np.float32)
+    got = O.resize_bicubic_tf(torch.from_numpy(v.reshape(1, 1, 4, 1)), (1, 8)).numpy().reshape(-1)
+    # first output: taps at -2, -1 fall outside; (0.8671875 * 1 - 0.0703125 * 2) / 0.796875
+    assert abs(got[0] - (0.8671875 * 1 - 0.0703125 * 2) / 0.796875) < 1e-6
+    # interior outputs of a linear ramp are the ramp itself at the half-pixel source location (cubic convolution is exact on lines)
+    np.testing.assert_allclose(got[3:5], [2.25, 2.75], atol=1e-6)                  # the two outputs whose four taps are inside
+    np.testing.assert_allclose(got, _bicubic_1d_analytic(v, 8), atol=1e-6)
+    # 5 -> 3 (no antialiasing: four taps at the scaled location): the middle output lands exactly on source pixel 2
+    v5 = np.array([0.0, 1.0, 4.0, 9.0, 16.0], np.float32)
+    got = O.resize_bicubic_tf(torch.from_numpy(v5.reshape(1, 5, 1, 1)), (3, 1)).numpy().reshape(-1)
+    assert abs(got[1] - 4.0) < 1e-6
+    np.testing.assert_allclose(got, _bicubic_1d_analytic(v5, 3), rtol=2e-3, atol=2e-3)     # offset 1/3 -> 341/1024 in the table
+
+
+def test_resize_bicubic_upscale_agrees_with_pillow():
+    """Pillow's BICUBIC (a = -0.5, half-pixel centres, support clipped to the image and renormalised) is the same filter when
+    UPSCALING (no antialias widening) -- an implementation that shares nothing with oracle/ops.py.  Difference: TensorFlow
+    reads the kernel from a 1024-entry table at the rounded offset."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    for (h, w), (oh, ow) in (((5, 7), (12, 9)), ((14, 14), (24, 24)), ((3, 4), (4, 11))):
+        img = rng.standard_normal((h, w)).astype(np.float32)
+        ref = np.asarray(Image.fromarray(img, mode="F").resize((ow, oh), Image.BICUBIC))
+        got = O.resize_bicubic_tf(torch.from_numpy(img.reshape(1, h, w, 1)), (oh, ow)).numpy().reshape(oh, ow)
+        assert np.abs(got - ref).max() <= 4e-3 * np.abs(ref).max(), ((h, w), (oh, ow), float(np.abs(got - ref).max()))
+
+
+def test_group_norm_hand_computed():
+    # one image, two pixels, four channels in two groups: group 0 = {1, 2, 5, 6} (mean 3.5, var 4.25), group 1 = {3, 4, 7, 8}
+    x = torch.tensor([[[[1., 2., 3., 4.], [5., 6., 7., 8.]]]])
+    gamma, beta = torch.tensor([1., 2., 1., 1.]), torch.tensor([0., 1., 0., 0.])
+    y = O.group_norm(x, gamma, beta, 2, 0.0).numpy().reshape(2, 4)
+    s = math.sqrt(4.25)
+    np.testing.assert_allclose(y[:, 0], [(1 - 3.5) / s, (5 - 3.5) / s], rtol=1e-6)
+    np.testing.assert_allclose(y[:, 1], [2 * (2 - 3.5) / s + 1, 2 * (6 - 3.5) / s + 1], rtol=1e-6)
+    np.testing.assert_allclose(y[:, 2], [(3 - 5.5) / s, (7 - 5.5) / s], rtol=1e-6)
+    # epsilon inside the square root: a constant group maps to beta
+    yc = O.group_norm(torch.ones(1, 1, 3, 4), gamma, beta, 2, 1e-5).numpy()
+    np.testing.assert_allclose(yc.reshape(3, 4), np.tile([0., 1., 0., 0.], (3, 1)), atol=1e-6)
+
+
+def test_blur_pool_hand_computed():
+    x = torch.arange(1., 10.).reshape(1, 3, 3, 1)
+    y = O.blur_pool2d(x, 1).numpy().reshape(3, 3)              # pad 1, REFLECT: row -1 is row 1, column -1 is column 1
+    assert abs(y[1, 1] - 80 / 16) < 1e-6                       # (1 + 4 + 3 + 8 + 20 + 12 + 7 + 16 + 9) / 16
+    assert abs(y[0, 0] - 48 / 16) < 1e-6                       # window [[5, 4, 5], [2, 1, 2], [5, 4, 5]]
+    y2 = O.blur_pool2d(torch.ones(1, 6, 6, 2), 2).numpy()      # stride 2: pad (3 + 2) // 2 - 1 = 1, 6 -> 3
+    assert y2.shape == (1, 3, 3, 2) and np.allclose(y2, 1.0)
+
+
+def test_conv2d_dilation_hand_computed():
+    x = torch.arange(7.).reshape(1, 1, 7, 1)
+    k = torch.ones(1, 3, 1, 1)
+    y = O.conv2d(x, k, dilation=2).numpy().reshape(-1)         # taps at x, x + 2, x + 4
+    np.testing.assert_allclose(y, [0 + 2 + 4, 1 + 3 + 5, 2 + 4 + 6])
+    ys = O.conv2d(x, k, dilation=2, padding="same").numpy().reshape(-1)    # effective kernel 5: pad (2, 2)
+    np.testing.assert_allclose(ys, [0 + 2, 1 + 3, 0 + 2 + 4, 1 + 3 + 5, 2 + 4 + 6, 3 + 5, 4 + 6])
+    d = O.depthwise_conv2d(torch.arange(14.).reshape(1, 1, 7, 2), torch.ones(1, 3, 2, 1), dilation=2).numpy().reshape(3, 2)
+    np.testing.assert_allclose(d, [[0 + 4 + 8, 1 + 5 + 9], [2 + 6 + 10, 3 + 7 + 11], [4 + 8 + 12, 5 + 9 + 13]])

@@ -197,3 +197,41 @@ def test_reference_rerun_reproduces_committed_fixture():
                        + names, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "identical to tests/golden/forward_golden.npz" in r.stdout
+
+
+# ---- weight ingestion rules: name map + first-conv adaptation, pinned to the reference's own functions --
+def test_name_map_of_every_variable_of_every_configuration_equals_the_reference_functions():
+    """tests/golden/reference_name_map.json holds, per configuration, a digest over (variable, PyTorch key, transposition
+    kind, layer name, weight name) computed by the REFERENCE's convert_tf_weight_name_to_pt_weight_name (utils/timm.py:39-106)
+    and _get_layer_name / _get_weight_name (models/factory.py:253-280), imported unmodified by
+    oracle/tools/make_name_map_golden.py.  The engine's functions must produce the same table for all 93 708 variables."""
+    import hashlib
+    from tfimm.models.factory import _layer_name
+    from tfimm.utils.timm import convert_tf_weight_name_to_pt_weight_name
+    with open(os.path.join(ROOT, "tests", "golden", "reference_name_map.json")) as f:
+        gold = json.load(f)
+    inv = _engine_inventories()
+    assert sorted(gold["digests"]) == sorted(inv) and len(inv) >= 196
+    total = 0
+    for name, (shapes, _) in inv.items():
+        lines = []
+        for k in sorted(shapes):
+            key, kind = convert_tf_weight_name_to_pt_weight_name(f"{name}/{k}:0", tuple(shapes[k]))
+            lines.append((k, key, kind, _layer_name(k), k))
+        total += len(lines)
+        if name in gold["tables"]:
+            assert [list(t) for t in lines] == gold["tables"][name], name      # readable diff for one model per family
+        assert hashlib.sha256("\n".join("|".join(t) for t in lines).encode()).hexdigest() == gold["digests"][name], name
+    assert total > 90000
+
+
+def test_first_conv_adaptation_equals_the_reference_function():
+    """_transform_first_conv (models/factory.py:282-305) run by oracle/tools/make_name_map_golden.py on a seeded kernel for
+    1 .. 8 input channels: sum for one channel, tile + rescale otherwise, biases untouched."""
+    from tfimm.models.factory import _transform_first_conv
+    g = np.load(os.path.join(ROOT, "tests", "golden", "first_conv_golden.npz"))
+    for c in range(1, 9):
+        got = _transform_first_conv(g["kernel"], c)
+        assert got.shape == g[f"kernel_in{c}"].shape
+        np.testing.assert_allclose(got, g[f"kernel_in{c}"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(_transform_first_conv(g["bias"], 4), g["bias_in4"])

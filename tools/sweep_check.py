@@ -9,7 +9,9 @@ import tfimm, oracle
 from tfimm.utils.init import synthetic_weights
 import model_checks as mc
 
-d = os.path.join(ROOT, "gpurun_out", "sweep")
+# SWEEP_DIR=sweep_fp32 SWEEP_TOL=1e-3: the float32 verification path's sweep (TFIMM_PRECISION=fp32 tools/sweep_forward.py)
+d = os.path.join(ROOT, "gpurun_out", os.environ.get("SWEEP_DIR", "sweep"))
+TOL = float(os.environ.get("SWEEP_TOL", mc.TOL_LOGITS))
 rows = []
 conditioned = []      # above the bar, but no further from the oracle than the oracle is from itself under bf16 weight rounding
 for f in sorted(glob.glob(os.path.join(d, "*.npy"))):
@@ -25,7 +27,7 @@ for f in sorted(glob.glob(os.path.join(d, "*.npy"))):
     err = mc.rel_err(got, ref)
     agree = float((got.argmax(-1) == ref.argmax(-1)).mean())
     note = ""
-    if err > mc.TOL_LOGITS:
+    if err > TOL and TOL >= mc.TOL_LOGITS:
         # Is it the engine or the problem?  The SAME fp32 oracle with its convolution / dense kernels and its input rounded to
         # bf16 (what the engine stores; nothing else changed): a random-init network of ~100 layers can amplify that rounding
         # alone beyond the bar (efficientnet_v2_xl: 0.34-0.49), and then the bar says nothing about the kernels.
@@ -41,7 +43,7 @@ for f in sorted(glob.glob(os.path.join(d, "*.npy"))):
     print(f"{name:45s} rel-to-max {err:.3e} top1 {agree:.2f}  ({time.time() - t0:.0f} s){note}", flush=True)
 errs = sorted(rows, reverse=True)
 print("\nworst:", [(n, f"{e:.2e}") for e, n, _ in errs[:8]])
-print(f"{len(rows)} models, {sum(e <= mc.TOL_LOGITS for e, _, _ in rows)} within {mc.TOL_LOGITS}"
+print(f"{len(rows)} models, {sum(e <= TOL for e, _, _ in rows)} within {TOL}"
       + (f"; above it but within 2x the oracle's own sensitivity to bf16-rounded kernels: {conditioned}" if conditioned else ""))
 for f in sorted(glob.glob(os.path.join(d, "*.err"))):
     print("ERROR", os.path.basename(f), open(f).read().strip()[:200])

@@ -13,7 +13,9 @@ import model_checks as mc
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 floor = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
-out = os.path.join(ROOT, "gpurun_out", "sweep")
+from tfimm.engine import precision
+# TFIMM_PRECISION=fp32: the float32 verification path (csrc/ref32.hip) -> gpurun_out/sweep_fp32, checked at 1e-3
+out = os.path.join(ROOT, "gpurun_out", "sweep_fp32" if precision.get() == "fp32" else "sweep")
 os.makedirs(out, exist_ok=True)
 names = [n for n in tfimm.list_models() if flt in n]
 t0 = time.time()
