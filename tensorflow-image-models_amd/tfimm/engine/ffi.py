@@ -177,3 +177,37 @@ def check(rc: int, what: str = ""):
     if rc != 0:
         msg = lib.tfimm_hip_last_error().decode("utf-8", "replace")
         raise HipError(f"{what or 'tfimm_hip call'} failed (rc={rc}): {msg}")
+
+
+# ---- roctx markers (TFIMM_ROCTX=1, graph.Plan.run): libroctx64 ships with ROCm; absent library = no markers, never an error
+_roctx = None
+
+
+def _roctx_lib():
+    global _roctx
+    if _roctx is None:
+        _roctx = False
+        # rocprofv3 (rocprofiler-sdk) traces its own roctx library; libroctx64 is the roctracer-era one
+        for name in ("librocprofiler-sdk-roctx.so", "libroctx64.so"):
+            try:
+                cand = C.CDLL(name)
+                cand.roctxRangePushA.argtypes = [C.c_char_p]
+                cand.roctxRangePushA.restype = C.c_int
+                cand.roctxRangePop.restype = C.c_int
+                _roctx = cand
+                break
+            except (OSError, AttributeError):
+                continue
+    return _roctx
+
+
+def roctx_push(label: str) -> None:
+    lib_ = _roctx_lib()
+    if lib_:
+        lib_.roctxRangePushA(label.encode("utf-8", "replace"))
+
+
+def roctx_pop() -> None:
+    lib_ = _roctx_lib()
+    if lib_:
+        lib_.roctxRangePop()

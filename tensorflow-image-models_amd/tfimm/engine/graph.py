@@ -1375,16 +1375,36 @@ class Plan:
             stream_ptr = torch.cuda.current_stream().cuda_stream
         st = C.c_void_p(stream_ptr)
         idx = self._input_patch[0]
+        # TFIMM_ROCTX=1: one roctx range per launch, named "<index> <op kind> <reference file:line>" -- rocprofv3
+        # --marker-trace then attributes kernel time to the reference call site each launch replaces
+        marks = self._roctx_labels() if os.environ.get("TFIMM_ROCTX", "0") == "1" else None
         for i, (fn, args) in enumerate(self.calls):
-            if i == idx:
-                rc = self.launch_input(x_dev, st, norm)
-            elif fn == "memset":
-                ffi.check(_hip_memset_async(args[0], args[1], stream_ptr), "hipMemsetAsync")
-                continue
-            else:
-                rc = fn(*args, st)
+            if marks is not None:
+                ffi.roctx_push(marks[i])
+            try:
+                if i == idx:
+                    rc = self.launch_input(x_dev, st, norm)
+                elif fn == "memset":
+                    ffi.check(_hip_memset_async(args[0], args[1], stream_ptr), "hipMemsetAsync")
+                    continue
+                else:
+                    rc = fn(*args, st)
+            finally:
+                if marks is not None:
+                    ffi.roctx_pop()
             if rc != 0:
                 ffi.check(rc, f"op {i} ({getattr(fn, '__name__', fn)})")
+
+    def _roctx_labels(self) -> List[str]:
+        """One label per entry of ``self.calls``: the op it belongs to (memsets sit in front of their op)."""
+        labels, ops = [], iter(self.prog.ops)
+        for fn, _ in self.calls:
+            if fn == "memset":
+                labels.append("memset (squeeze sums)")
+                continue
+            op = next(ops)
+            labels.append(f"{len(labels)} {op.kind} {op.cite}".strip())
+        return labels
 
 
 class CapturedPlan:
