@@ -348,9 +348,21 @@ def cpu_baseline(model, name, target_seconds=20.0, parity_images=1024):
         return ((rng.random((b, *cfg.input_size, cfg.in_channels), dtype=np.float32) - mean) / std).astype(np.float32)
 
     w = model.weights
-    xs, ys = [batch_()], []
+    poolable = type(model).__name__ in ("ResNet", "EfficientNet", "ViT", "SwinTransformer", "CaiT")   # classifier input = pooled "features"
+
+    def fwd(x):
+        """logits (+ the classifier's input: the pooled "features" entry of the reference's feature dictionary)"""
+        if not poolable:
+            return oracle.forward(cfg, w, x), None
+        y, feats = oracle.forward(cfg, w, x, return_features=True)
+        f = np.asarray(feats["features"], dtype=np.float32)
+        return y, (f if f.ndim == 2 else f.reshape(f.shape[0], -1, f.shape[-1]).mean(1))
+
+    xs, ys, fs = [batch_()], [], []
     t0 = time.perf_counter()
-    ys.append(oracle.forward(cfg, w, xs[0]))           # warm-up, also the first parity batch
+    y0, f0 = fwd(xs[0])                                # warm-up, also the first parity batch
+    ys.append(y0)
+    fs.append(f0)
     first = time.perf_counter() - t0
     need = -(-parity_images // b) - 1                 # forwards that fill the parity sample ...
     n = max(7, min(need, int(target_seconds / max(first, 1e-3)) - 1))      # ... bounded by the time budget (>= 64 images)
@@ -358,18 +370,48 @@ def cpu_baseline(model, name, target_seconds=20.0, parity_images=1024):
     for _ in range(n):
         x = batch_()
         t0 = time.perf_counter()
-        y = oracle.forward(cfg, w, x)
+        y, f = fwd(x)
         dt += time.perf_counter() - t0
         if len(xs) * b < parity_images:
             xs.append(x)
             ys.append(y)
+            fs.append(f)
+    feats = None if (not poolable or any(f is None for f in fs)) else np.concatenate(fs)
     return (dict(value=round(b * n / dt, 2), unit="images/sec", cores=cores, kind="port",
                  sample=f"{n} forwards of batch {b} ({name}, fp32 torch-CPU restatement of the reference's forward, pinned "
                         f"to the reference's own code in tests/test_golden.py; TensorFlow itself is unavailable)"),
-            np.concatenate(xs), np.concatenate(ys))
+            np.concatenate(xs), np.concatenate(ys), feats)
 
 
-def parity_statement(model, xs, ys):
+def calibrated_head(model, feats, nb_classes):
+    """A classifier head with NON-TRIVIAL MARGINS for the parity images.  With random-init weights on
+    uniform-noise images the 1000 logits of every image are nearly the same near-Gaussian vector, so "top-1 match" with the
+    random head says little.  Here the first n_anchor = min(images, classes, feature width / 2) parity images become the
+    prototypes of classes 0 .. n_anchor-1: W^T (f_i - mean f) ~ e_i by ridge regression on the ORACLE's classifier-input
+    features (lambda = 1e-3 of the mean eigenvalue), remaining classes get zero weights and bias -1.  Returns
+    (kernel [D][classes], bias [classes], n_anchor) or None when the model's classifier does not read the pooled features."""
+    import numpy as np
+    if feats is None or not hasattr(model.cfg, "classifier") or isinstance(model.cfg.classifier, (list, tuple)):
+        return None
+    w = model.weights
+    kname = next((k for k in w if k.endswith(f"{model.cfg.classifier}/kernel")), None)
+    if kname is None or w[kname].ndim != 2 or w[kname].shape[0] != feats.shape[1]:
+        return None
+    d = feats.shape[1]
+    n = int(min(feats.shape[0], nb_classes, d // 2))
+    f64 = feats.astype(np.float64)
+    fbar = f64.mean(0)
+    fc = f64[:n] - fbar
+    g = fc @ fc.T
+    wt = np.linalg.solve(g + 1e-3 * np.trace(g) / n * np.eye(n), fc)       # [n][D]: row i = the weights of class i
+    kernel = np.zeros((d, nb_classes), np.float32)
+    kernel[:, :n] = wt.T
+    bias = np.full(nb_classes, -1.0, np.float32)
+    bias[:n] = -(wt @ fbar)
+    return kname, kernel, bias, n
+
+
+def parity_statement(model, xs, ys, feats=None):
     """Engine vs oracle on the parity images (every forward the CPU baseline timed, up to 1024 distinct synthetic images):
     * the bf16 product path: rel-to-max error, top-1 match, and the match restricted to images whose ORACLE top-1 / top-2
       margin is at least 10x that image's own error (where an argmax is decided by the kernels rather than by rounding);
@@ -416,6 +458,35 @@ def parity_statement(model, xs, ys):
                                      "the reference's own bar is 1e-3 (tests/test_timm.py:71)")
     except Exception as e:  # noqa: BLE001
         out["fp32_path"] = {"error": f"{type(e).__name__}: {e}"}
+    # the same images through a head with real margins: each anchor image is its own class
+    try:
+        cal = calibrated_head(model, feats, ys.shape[-1])
+        if cal is not None:
+            kname, kernel, bias, n_anchor = cal
+            bname = kname[:-len("kernel")] + "bias"
+            orig = {kname: model.weights[kname].copy(), bname: model.weights[bname].copy()}
+            ref = feats.astype(np.float32) @ kernel + bias                    # the oracle's logits with that head (Dense: x @ W + b)
+            model.set_weights({kname: kernel, bname: bias}, strict=False)
+            try:
+                got_c = run(xs).reshape(ref.shape)
+            finally:
+                model.set_weights(orig, strict=False)
+            a = slice(0, n_anchor)                                            # anchors: own class by construction
+            err_c = np.abs(got_c - ref).max(-1)
+            top = np.sort(ref, -1)
+            margin_c = top[:, -1] - top[:, -2]
+            miss_c = got_c.argmax(-1) != ref.argmax(-1)
+            out["calibrated_head"] = dict(
+                images=int(ref.shape[0]), anchors=int(n_anchor),
+                oracle_top1_is_own_class=float((ref[a].argmax(-1) == np.arange(n_anchor)).mean()),
+                top1_match=float(1.0 - miss_c.mean()), top1_match_anchors=float(1.0 - miss_c[a].mean()),
+                median_margin_over_own_err_anchors=float(np.median(margin_c[a] / np.maximum(err_c[a], 1e-30))),
+                min_margin_over_own_err_anchors=float((margin_c[a] / np.maximum(err_c[a], 1e-30)).min()),
+                rel_to_max_err=float(np.abs(got_c - ref).max() / (np.abs(ref).max() + 1e-6)),
+                what="classifier replaced by a ridge-regression prototype head fitted on the oracle's pooled features (anchor image i "
+                     "= class i), same backbone weights, same images: the engine must single out every image among the anchors")
+    except Exception as e:  # noqa: BLE001
+        out["calibrated_head"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 
@@ -447,13 +518,13 @@ def run_workload(name, args, world, rank, dist, steps, warmup, batch=0, micro_ba
                    mfma_frac_whole_step=round(flops_img * batch / ms / 1e9 / 2500.0, 4),
                    roofline=roofline_of(name, wl, r, steps, batch))
         if with_cpu:
-            cpu, xs, ys = cpu_baseline(model, wl["model"])
+            cpu, xs, ys, fs = cpu_baseline(model, wl["model"])
             out["cpu_baseline"] = cpu
-            out["parity_vs_oracle"] = parity_statement(model, xs, ys)
+            out["parity_vs_oracle"] = parity_statement(model, xs, ys, fs)
         elif with_parity:
             # N > 1: the CPU baseline is an N = 1 figure, but rank 0 still states parity of what it just ran
-            _, xs, ys = cpu_baseline(model, wl["model"], target_seconds=1.0)
-            out["parity_vs_oracle"] = parity_statement(model, xs, ys)
+            _, xs, ys, fs = cpu_baseline(model, wl["model"], target_seconds=1.0)
+            out["parity_vs_oracle"] = parity_statement(model, xs, ys, fs)
     del r, model
     torch.cuda.empty_cache()
     return out
