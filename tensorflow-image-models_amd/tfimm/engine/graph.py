@@ -1239,12 +1239,17 @@ class Plan:
             tuned += 1
         return tuned
 
-    def autotune_in_context(self, x_dev, top: int = 4, iters: int = 3, verbose: bool = False) -> int:
+    def autotune_in_context(self, x_dev, top: int = 4, iters: int = 3, verbose: bool = False,
+                            challengers: Optional[Tuple[int, ...]] = None, min_gain: float = 0.0) -> int:
         """Second tuning pass.  ``autotune`` times a GEMM back to back with itself -- operands warm in
         L2 / Infinity Cache, which flatters tiles that re-read them.  Here the ``top`` fastest tiles of
         that pass are timed INSIDE a full forward (HIP events around the one launch, every other layer
         running as it will), summed over all layers that share the problem shape; the table keeps the
-        winner.  Returns the number of shapes whose choice changed."""
+        winner.  Returns the number of shapes whose choice changed.
+
+        ``challengers``: instead of the isolated pass' ranking, time the table's CURRENT choice against these hints (a new
+        kernel entering an existing table: tools/retune_with.py); a challenger replaces the incumbent only when it is at
+        least ``min_gain`` (fraction) faster."""
         import torch
         groups: Dict[str, List[int]] = {}
         for gi, d in enumerate(self._gemm_descs):
@@ -1275,13 +1280,19 @@ class Plan:
 
         changed = 0
         for key, members in groups.items():
-            times = self._tune_times.get(key)
-            if not times or len(times) < 2:
-                continue
-            cands = [h for h, _ in sorted(times.items(), key=lambda kv: kv[1])[:top]]
+            if challengers is not None:
+                allowed = tune.candidates_for(self._gemm_descs[members[0]])
+                cands = [tune.TABLE.get(key, 0)] + [h for h in challengers if h in allowed and h != tune.TABLE.get(key, 0)]
+                if len(cands) < 2:
+                    continue
+            else:
+                times = self._tune_times.get(key)
+                if not times or len(times) < 2:
+                    continue
+                cands = [h for h, _ in sorted(times.items(), key=lambda kv: kv[1])[:top]]
             call_ids = {self._gemm_call_index[gi] for gi in members}
             best, best_ms = tune.TABLE.get(key, 0), float("inf")
-            for hint in cands:
+            for ci, hint in enumerate(cands):
                 for gi in members:
                     self._gemm_descs[gi].tile_hint = hint
                 ms = [forward_timed(call_ids) for _ in range(iters + 1)][1:]
@@ -1290,7 +1301,7 @@ class Plan:
                 m = min(ms)
                 if verbose:
                     print(f"in-context {key} hint={hint} {m * 1e3:.1f} us")
-                if m < best_ms:
+                if m < best_ms * (1.0 - (min_gain if (challengers is not None and ci > 0) else 0.0)):
                     best, best_ms = hint, m
             if best != tune.TABLE.get(key):
                 changed += 1
