@@ -531,6 +531,36 @@ TFIMM_API int tfimm_hip_ref_talking_heads_attention(const tfimm_tha_desc* d, voi
 TFIMM_API int tfimm_hip_ref_class_attention(const void* q, const void* kv, void* out, int B, int n_tokens, int heads, int hd,
                                             int ldq, int ldkv, int ldo, void* stream);
 
+/* =======================================================================================
+ * PROGRAM-LEVEL ENTRY POINTS (csrc/plan.hip): a whole forward behind three calls, for hosts without Python.
+ *
+ * Lowering a model configuration to the call sequence above (weight packing, buffer plan, tile selection) is host logic
+ * (tfimm/engine/graph.py).  `Plan.export()` serialises the FINISHED plan of one (model, batch size) -- every call with its
+ * arguments, the packed constants, the slab sizes, the named outputs -- into a self-contained blob; these functions run it
+ * by calling the very same op-level entry points with the very same arguments (bit-identical results).  Conventions as
+ * everywhere else: the caller owns the device memory (ONE workspace of tfimm_plan_info.workspace_bytes, 256-byte aligned),
+ * every launch is asynchronous on `stream` and capturable into a hipGraph, nothing allocates on the device.
+ *
+ *   tfimm_hip_plan_query    parse the blob: workspace size, batch, input geometry
+ *   tfimm_hip_plan_create   upload the constants into `workspace` (synchronises `stream` once; the blob may be freed
+ *                           afterwards) and resolve every pointer of the call list
+ *   tfimm_hip_plan_forward  input: [batch][in_h][in_w][in_c] NHWC, in_dtype 0 = float32, 1 = bf16 (device pointer)
+ *   tfimm_hip_plan_output   where a named result lies ("logits", or a feature name of a plan exported with features):
+ *                           device pointer into the workspace, rows (= batch * rows per image), columns, dtype (0 bf16, 1 f32)
+ * A plan object is not re-entrant (one forward at a time); distinct plans are independent.
+ * ======================================================================================= */
+typedef void* tfimm_plan_t;
+typedef struct tfimm_plan_info {
+  uint64_t workspace_bytes;
+  int32_t batch, in_h, in_w, in_c;
+  int32_t n_calls, n_outputs;
+} tfimm_plan_info;
+TFIMM_API int tfimm_hip_plan_query(const void* blob, size_t bytes, tfimm_plan_info* info);
+TFIMM_API int tfimm_hip_plan_create(const void* blob, size_t bytes, void* workspace, void* stream, tfimm_plan_t* plan);
+TFIMM_API int tfimm_hip_plan_forward(tfimm_plan_t plan, const void* input, int in_dtype, void* stream);
+TFIMM_API int tfimm_hip_plan_output(tfimm_plan_t plan, const char* name, void** ptr, int64_t* rows, int64_t* cols, int* dtype);
+TFIMM_API int tfimm_hip_plan_destroy(tfimm_plan_t plan);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,6 +128,12 @@ SYMBOLS = {
     "tfimm_hip_eca_gate": (_i, [_vp, _f, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tfimm_hip_grouped_conv3x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "tfimm_hip_bias_act": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
+    # program-level entry points (csrc/plan.hip): a serialised plan (graph.Plan.export) run without Python host logic
+    "tfimm_hip_plan_query": (_i, [_vp, C.c_size_t, _vp]),
+    "tfimm_hip_plan_create": (_i, [_vp, C.c_size_t, _vp, _vp, C.POINTER(_vp)]),
+    "tfimm_hip_plan_forward": (_i, [_vp, _vp, _i, _vp]),
+    "tfimm_hip_plan_output": (_i, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i)]),
+    "tfimm_hip_plan_destroy": (_i, [_vp]),
     # float32 verification path (csrc/ref32.hip): the bf16 signatures with float tensors
     "tfimm_hip_ref_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "tfimm_hip_ref_cast_input": (_i, [_vp, _i, _vp, _i64, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
@@ -148,6 +154,11 @@ SYMBOLS = {
     "tfimm_hip_ref_class_attention": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tfimm_hip_memset_async": (_i, [_vp, _i, C.c_size_t, _vp]),
 }
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [("workspace_bytes", C.c_uint64), ("batch", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32),
+                ("in_c", C.c_int32), ("n_calls", C.c_int32), ("n_outputs", C.c_int32)]
 
 
 class HipError(RuntimeError):

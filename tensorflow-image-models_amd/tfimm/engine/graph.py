@@ -1310,6 +1310,139 @@ class Plan:
                 self._gemm_descs[gi].tile_hint = best
         return changed
 
+    def export(self) -> bytes:
+        """This plan as a self-contained blob for the program-level C entry points (csrc/plan.hip, include/tfimm_hip.h:
+        tfimm_hip_plan_query / _create / _forward / _output): every call with its arguments, the packed constants, the slab
+        sizes and the named outputs.  Device pointers are written symbolically -- (slab, offset), (constant, offset), the
+        caller's input -- and resolved against the caller's workspace by tfimm_hip_plan_create, so a host without Python runs
+        exactly the launches this plan would (bit-identical results)."""
+        import struct
+        import torch
+        if self.prog.precision != "bf16":
+            raise NotImplementedError("plans of the float32 verification path are not exported")
+        if self.device == "cpu":
+            raise RuntimeError("export needs a plan built on the GPU (tile hints and occupancy are resolved there)")
+        consts = self.prog._dev_consts
+        hosts: List[np.ndarray] = []
+        for k in self._keepalive:
+            if isinstance(k, dict):
+                hosts.extend(v for v in k.values() if isinstance(v, np.ndarray))
+        ranges = ([(t.data_ptr(), max(t.numel() * t.element_size(), 1), 3, i) for i, t in enumerate(self.slabs)]
+                  + [(t.data_ptr(), max(t.numel() * t.element_size(), 1), 4, i) for i, t in enumerate(consts)]
+                  + [(h.ctypes.data, max(h.nbytes, 1), 5, i) for i, h in enumerate(hosts)])
+
+        def ptr_ref(v):
+            """(kind, aux, value) of a raw pointer value: NULL, or an offset into a slab / constant / host array"""
+            if not v:
+                return (2, 0, 0)
+            for base, size, kind, idx in ranges:
+                if base <= v < base + size:
+                    return (kind, idx, v - base)
+            for base, size, kind, idx in ranges:          # one past the end of a buffer (never dereferenced)
+                if v == base + size:
+                    return (kind, idx, v - base)
+            raise ValueError(f"pointer {v:#x} is outside every buffer of the plan")
+
+        structs: List[Tuple[bytes, list]] = []
+        struct_ids: Dict[int, int] = {}
+
+        def struct_ref(obj):
+            if id(obj) in struct_ids:
+                return struct_ids[id(obj)]
+            raw = bytearray(bytes(obj))
+            relocs = []
+            for fname, ftype in obj._fields_:
+                if ftype is C.c_void_p:
+                    off = getattr(type(obj), fname).offset
+                    relocs.append((off,) + ptr_ref(getattr(obj, fname)))
+                    raw[off:off + 8] = b"\0" * 8
+            structs.append((bytes(raw), relocs))
+            struct_ids[id(obj)] = len(structs) - 1
+            return len(structs) - 1
+
+        def arg_ref(a, ctype):
+            if ctype is C.c_void_p:
+                return ptr_ref(a if isinstance(a, int) or a is None else getattr(a, "value", a))
+            if hasattr(ctype, "_type_") and isinstance(ctype._type_, type) and issubclass(ctype._type_, C.Structure):
+                return (7, struct_ref(a._obj), 0)
+            if ctype is C.c_float:
+                return (1, 0, struct.unpack("<Q", struct.pack("<d", float(a)))[0])
+            return (0, 0, int(a) & 0xFFFFFFFFFFFFFFFF)
+
+        stem_call = stem_desc = None
+        pad_t = pad_l = 0
+        if self._stem_raw is not None:
+            # the fused ResNet stem can read the caller's image itself: exported pointing at the converted copy, the executor
+            # re-points it per forward (tfimm_hip_plan_forward)
+            stem_desc, padded_ptr, _, _, pad_t, pad_l = self._stem_raw
+            stem_desc.x, stem_desc.in_dtype = padded_ptr, 0
+            stem_call = next(i for i, (fn, a) in enumerate(self.calls) if a and getattr(a[0], "_obj", None) is stem_desc)
+        calls = []
+        idx = self._input_patch[0]
+        for i, (fn, args) in enumerate(self.calls):
+            if fn == "memset":
+                calls.append(("memset", [ptr_ref(args[0]), (0, 0, int(args[1]))]))
+                continue
+            if i == idx:
+                fn = self._input_call[0]
+                args = (None, 0) + tuple(self._input_call[1])
+                refs = [(6, 0, 0)] + [arg_ref(a, t) for a, t in list(zip(args, fn.argtypes))[1:]]
+            else:
+                refs = [arg_ref(a, t) for a, t in zip(args, fn.argtypes)]
+            calls.append((fn.__name__, refs))
+        stem_struct = struct_ids[id(stem_desc)] if stem_desc is not None else -1
+        stem_call = -1 if stem_call is None else stem_call
+        H, W, cin = self.prog.input_shape
+
+        def build(const_offsets, host_offsets):
+            out = bytearray()
+            out += struct.pack("<IIIIiii", 0x4c504654, 1, self.ffi.lib.tfimm_hip_abi_version(), self.batch, H, W, cin)
+            out += struct.pack("<I", len(self.slabs)) + b"".join(struct.pack("<Q", n) for n in self.slab_bytes)
+            out += struct.pack("<I", len(consts))
+            for t, off in zip(consts, const_offsets):
+                out += struct.pack("<QQ", t.numel() * t.element_size(), off)
+            out += struct.pack("<I", len(hosts))
+            for h, off in zip(hosts, host_offsets):
+                out += struct.pack("<QQ", h.nbytes, off)
+            out += struct.pack("<I", len(structs))
+            for raw, relocs in structs:
+                out += struct.pack("<II", len(raw), len(relocs)) + raw
+                for off, kind, aux, value in relocs:
+                    out += struct.pack("<IIIQ", off, kind, aux, value)
+            out += struct.pack("<I", len(calls))
+            for name, refs in calls:
+                nb = name.encode()
+                out += struct.pack("<I", len(nb)) + nb + struct.pack("<I", len(refs))
+                for kind, aux, value in refs:
+                    out += struct.pack("<IIQ", kind, aux, value)
+            out += struct.pack("<iiiii", idx, stem_call, stem_struct, pad_t, pad_l)
+            out += struct.pack("<I", len(self.prog.outputs))
+            for name, t in self.prog.outputs.items():
+                nb = name.encode()
+                out += struct.pack("<I", len(nb)) + nb
+                out += struct.pack("<IQQQI", self.assign[t.id], 0, t.rows, t.C, 1 if t.dtype == "f32" else 0)
+            return out
+
+        head = build([0] * len(consts), [0] * len(hosts))
+        pos = (len(head) + 255) // 256 * 256
+        const_offsets, host_offsets, data = [], [], []
+        for t in consts:
+            b = t.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes() if t.numel() else b""
+            const_offsets.append(pos)
+            data.append((pos, b))
+            pos = (pos + len(b) + 255) // 256 * 256
+        for h in hosts:
+            b = np.ascontiguousarray(h).tobytes()
+            host_offsets.append(pos)
+            data.append((pos, b))
+            pos = (pos + len(b) + 255) // 256 * 256
+        blob = bytearray(pos)
+        head = build(const_offsets, host_offsets)
+        blob[:len(head)] = head
+        for off, b in data:
+            blob[off:off + len(b)] = b
+        return bytes(blob)
+
     def capture(self, x_dev, norm=None) -> "CapturedPlan":
         return CapturedPlan(self, x_dev, norm)
 

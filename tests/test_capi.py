@@ -114,3 +114,20 @@ def test_new_entry_points_validate_before_any_launch():
     z3 = (ctypes.c_float * 3)(1.0, 0.0, 1.0)
     assert ffi.lib.tfimm_hip_preprocess_input(p, p, 16, 3, 4, m9, z3, None) == -1             # std == 0
     assert ffi.lib.tfimm_hip_preprocess_input_pad(p, p, 1, 4, 4, 5, 0, 0, 0, 0, m9, m9, None) == -1   # c_in > 4
+
+
+def test_plan_info_layout_and_blob_validation_without_gpu():
+    """program-level entry points (csrc/plan.hip): the info struct mirrors the header, a blob that is not a plan is refused
+    before anything touches the device"""
+    hdr = open(os.path.join(ROOT, "include", "tfimm_hip.h")).read()
+    body = hdr[hdr.index("typedef struct tfimm_plan_info {"):hdr.index("} tfimm_plan_info;")]
+    names = [tok.strip() for line in body.splitlines()[1:] for tok in line.split(";")[0].replace("uint64_t", "").replace("int32_t", "").split(",")
+             if tok.strip()]
+    assert names == [f[0] for f in ffi.PlanInfo._fields_], names
+    assert ctypes.sizeof(ffi.PlanInfo) == 8 + 6 * 4
+    info = ffi.PlanInfo()
+    junk = b"not a plan" * 10
+    lib = ffi.lib
+    assert lib.tfimm_hip_plan_query(junk, len(junk), ctypes.byref(info)) == -1
+    assert b"plan" in lib.tfimm_hip_last_error()
+    assert lib.tfimm_hip_plan_query(None, 0, ctypes.byref(info)) == -1
