@@ -16,12 +16,12 @@ res = torch.randn(M, N, device="cuda").to(torch.bfloat16) if len(sys.argv) > 6 a
 act = sys.argv[7] if len(sys.argv) > 7 else ""
 out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
 for _ in range(2):
-    H.gemm(a, w, N, K, bias=bias, out=out, tile_hint=hint, residual=res, act=act)
+    H.gemm(a, w, N, K, bias=bias, out=out, tile_hint=("table" if hint == 0 else hint), residual=res, act=act, act_after_res=res is not None)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(iters):
-    H.gemm(a, w, N, K, bias=bias, out=out, tile_hint=hint, residual=res, act=act)
+    H.gemm(a, w, N, K, bias=bias, out=out, tile_hint=("table" if hint == 0 else hint), residual=res, act=act, act_after_res=res is not None)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
 gb = (M * K + M * N * (2 if res is not None else 1)) * 2 / 1e9
