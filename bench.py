@@ -48,6 +48,7 @@ WORKLOADS = {
     "efficientnet_b4": dict(model="efficientnet_b4", batch=256, bound="hbm", family=("gemm", "dwconv")),
     "vit_tiny_patch16_224": dict(model="vit_tiny_patch16_224", batch=1, bound="mfma", family=("gemm",)),
     "convnext_tiny": dict(model="convnext_tiny", batch=256, bound="hbm", family=("gemm", "dwconv")),
+    "convnext_base": dict(model="convnext_base", batch=256, bound="hbm", family=("gemm", "dwconv")),
     "cait_xxs24_224": dict(model="cait_xxs24_224", batch=256, bound="mfma", family=("gemm",)),
 }
 DEFAULT_EXTRA = "vit_base_patch16_224,swin_base_patch4_window7_224,efficientnet_b4"
@@ -219,7 +220,7 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
                 eager_ms_per_step=None if eager_dt is None else eager_dt / steps * 1e3)
 
 
-_EVENT_KINDS = {"gemm": "gemm", "stem_pool": "gemm", "conv_chain": "gemm", "grouped_conv": "gemm", "dwconv": "dwconv",
+_EVENT_KINDS = {"gemm": "gemm", "stem_pool": "gemm", "conv_chain": "gemm", "mlp_fused": "gemm", "grouped_conv": "gemm", "dwconv": "dwconv",
                 "expand_dwconv": "dwconv", "attention": "attention", "talking_heads_attention": "attention"}
 
 
@@ -238,7 +239,7 @@ def run_with_events(plan, x_dev, events):
     B = plan.batch
     by_fn = {id(lib.tfimm_hip_gemm): "gemm", id(lib.tfimm_hip_stem_conv_pool): "stem_pool",
              id(lib.tfimm_hip_conv_chain): "conv_chain", id(lib.tfimm_hip_grouped_conv3x3): "grouped_conv",
-             id(lib.tfimm_hip_expand_dwconv): "expand_dwconv",
+             id(lib.tfimm_hip_expand_dwconv): "expand_dwconv", id(lib.tfimm_hip_mlp_fused): "mlp_fused",
              id(lib.tfimm_hip_dwconv): "dwconv", id(lib.tfimm_hip_attention): "attention",
              id(lib.tfimm_hip_talking_heads_attention): "talking_heads_attention"}     # ctypes functions are not hashable
     cache = plan.__dict__.setdefault("_timed_ops", {})

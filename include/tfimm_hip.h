@@ -485,6 +485,32 @@ TFIMM_API int tfimm_hip_memset_async(void* dst, int value, size_t bytes, void* s
 TFIMM_API int tfimm_hip_bias_act(const void* x, const float* bias, void* y, int64_t rows, int C, int act,
                        void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * tfimm_hip_mlp_fused: out = residual + fc2( act( fc1( LayerNormalization(x) ) ) ) in ONE launch -- norm2 / mlp.fc1 / GELU /
+ * mlp.fc2 / shortcut add of a Swin block (swin.py:322-325, layers/transformers.py:208-214), norm / fc1 / GELU / fc2 (/ LayerScale,
+ * folded into w2 / b2) / shortcut add of a ConvNeXt block (convnext.py:226-232).  The hidden tensor is never written: the bf16-packed
+ * accumulators of the first GEMM are the register operand of the second (csrc/mlp.hip).  Built for C = 128, hidden = 512.
+ *   x, residual, out  bf16 [M][C] (residual may alias x)
+ *   w1   bf16 [hidden][C], LayerNorm gamma folded in (W1' = gamma * W1, then rounded);  b1 fp32 [hidden] = beta . W1 + b1;  the
+ *        kernel normalises the rows itself: (x - mean) * rstd (two-pass statistics, eps), rounded to bf16, is what W1' multiplies
+ *   w2   bf16 [C][hidden] with its K axis in tfimm/engine/pack.py chain_k_order (within every 16 channels the two middle quads
+ *        swapped);  b2 fp32 [C]
+ * Anything else returns TFIMM_EUNSUP and the caller runs tfimm_hip_row_stats + two tfimm_hip_gemm launches.
+ * ------------------------------------------------------------------------------------- */
+typedef struct tfimm_mlp_desc {
+  const void* x;
+  const void* w1;
+  const float* b1;
+  const void* w2;
+  const float* b2;
+  const void* residual;
+  void* out;
+  int64_t M;
+  int32_t C, hidden, act;
+  float eps;
+} tfimm_mlp_desc;
+TFIMM_API int tfimm_hip_mlp_fused(const tfimm_mlp_desc* d, void* stream);
+
 /* =======================================================================================
  * FLOAT32 VERIFICATION PATH (csrc/ref32.hip; selected by TFIMM_PRECISION=fp32, tfimm/engine/precision.py)
  *

@@ -87,6 +87,7 @@ const std::map<std::string, Entry>& table() {
   static const std::map<std::string, Entry> t = {
       TFIMM_ADAPTER(tfimm_hip_gemm, const tfimm_gemm_desc*),
       TFIMM_ADAPTER(tfimm_hip_conv_chain, const tfimm_chain_desc*),
+      TFIMM_ADAPTER(tfimm_hip_mlp_fused, const tfimm_mlp_desc*),
       TFIMM_ADAPTER(tfimm_hip_expand_dwconv, const tfimm_expand_dw_desc*),
       TFIMM_ADAPTER(tfimm_hip_stem_conv_pool, const tfimm_stem_desc*),
       TFIMM_ADAPTER(tfimm_hip_attention, const tfimm_attn_desc*),

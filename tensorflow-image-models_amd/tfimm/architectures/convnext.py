@@ -123,10 +123,14 @@ class ConvNeXt(Model):
                 p = f"stages/{j}/blocks/{i}/"
                 y, _ = b.dwconv(x, p + "conv_dw/depthwise_kernel", stride=1, padding=3, bias=p + "conv_dw/bias",
                                 cite="convnext.py:224-225")
-                h = b.ln_dense(y, p + "norm", eps, p + "mlp/fc1/kernel", p + "mlp/fc1/bias", act=c.act_layer,
-                               cite_ln="convnext.py:226", cite="transformers.py:209-210")
-                x = b.dense(h, p + "mlp/fc2/kernel", p + "mlp/fc2/bias", out_scale=p + "gamma", residual=x,
-                            cite="transformers.py:212 + convnext.py:228-230")
+                z = b.mlp_fused(y, p + "norm", eps, p + "mlp/fc1", p + "mlp/fc2", act=c.act_layer, residual=x,
+                                out_scale=p + "gamma", cite="convnext.py:226-232, transformers.py:208-214")
+                if z is None:
+                    h = b.ln_dense(y, p + "norm", eps, p + "mlp/fc1/kernel", p + "mlp/fc1/bias", act=c.act_layer,
+                                   cite_ln="convnext.py:226", cite="transformers.py:209-210")
+                    z = b.dense(h, p + "mlp/fc2/kernel", p + "mlp/fc2/bias", out_scale=p + "gamma", residual=x,
+                                cite="transformers.py:212 + convnext.py:228-230")
+                x = z
                 if want_features:
                     b.p.mark_output(f"stage_{j}/block_{i}", x)
         b.p.mark_output("conv_features", x)

@@ -173,9 +173,14 @@ class SwinTransformer(Model):
                 a = b.attention(qkv, nh, (D // nh) ** -0.5, window=ws, shift=shift, res=res,
                                 rel_bias=np.ascontiguousarray(bias), cite="swin.py:299-313 + 168-195", name=p + "attn")
                 x = b.dense(a, p + "attn/proj/kernel", p + "attn/proj/bias", residual=x, cite="swin.py:196,318")
-                hdn = b.ln_dense(x, p + "norm2", eps, p + "mlp/fc1/kernel", p + "mlp/fc1/bias", act=c.act_layer,
-                                 cite_ln="swin.py:322", cite="transformers.py:209-210")
-                x = b.dense(hdn, p + "mlp/fc2/kernel", p + "mlp/fc2/bias", residual=x, cite="transformers.py:212, swin.py:325")
+                y = b.mlp_fused(x, p + "norm2", eps, p + "mlp/fc1", p + "mlp/fc2", act=c.act_layer,
+                                cite="swin.py:322-325, transformers.py:208-214")
+                if y is None:
+                    hdn = b.ln_dense(x, p + "norm2", eps, p + "mlp/fc1/kernel", p + "mlp/fc1/bias", act=c.act_layer,
+                                     cite_ln="swin.py:322", cite="transformers.py:209-210")
+                    y = b.dense(hdn, p + "mlp/fc2/kernel", p + "mlp/fc2/bias", residual=x,
+                                cite="transformers.py:212, swin.py:325")
+                x = y
                 x.H, x.W = res
                 if want_features:
                     b.p.mark_output(f"block_{k}", x)

@@ -93,6 +93,12 @@ class ExpandDwDesc(C.Structure):
     ]
 
 
+class MlpDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p),
+                ("b2", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p), ("M", C.c_int64),
+                ("C", C.c_int32), ("hidden", C.c_int32), ("act", C.c_int32), ("eps", C.c_float)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/tfimm_hip.h
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SYMBOLS = {
@@ -101,6 +107,7 @@ SYMBOLS = {
     "tfimm_hip_device_info": (_i, [_i, C.c_char_p, _i]),
     "tfimm_hip_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "tfimm_hip_conv_chain": (_i, [C.POINTER(ChainDesc), _vp]),
+    "tfimm_hip_mlp_fused": (_i, [C.POINTER(MlpDesc), _vp]),
     "tfimm_hip_expand_dwconv": (_i, [C.POINTER(ExpandDwDesc), _vp]),
     "tfimm_hip_stem_conv_pool": (_i, [C.POINTER(StemDesc), _vp]),
     "tfimm_hip_cast_input": (_i, [_vp, _i, _vp, _i64, _i, _i, _vp]),

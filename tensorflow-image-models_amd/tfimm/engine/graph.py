@@ -117,7 +117,7 @@ class Program:
             a = op.attrs
             if op.kind in ("gemm", "stem_pool"):
                 total += 2 * a["M"] * a["N"] * a["K_true"]
-            elif op.kind in ("attention", "talking_heads_attention", "conv_chain"):
+            elif op.kind in ("attention", "talking_heads_attention", "conv_chain", "mlp_fused"):
                 total += a["flops"]
             elif op.kind == "dwconv":
                 total += 2 * a["OH"] * a["OW"] * a["C"] * a["k"] * a["k"]
@@ -579,6 +579,32 @@ class Builder:
             return self.dense(x, kernel, bias, act=act, ln=(ln_prefix, eps, self.row_stats(x, eps, cite=cite_ln)),
                               cite=(cite_ln + ", " + cite) if cite_ln else cite)
         return self.dense(self.layernorm(x, ln_prefix, eps, cite=cite_ln), kernel, bias, act=act, cite=cite)
+
+    def mlp_fused(self, x: TRef, ln_prefix: str, eps: float, fc1: str, fc2: str, *, act="gelu", residual: Optional[TRef] = None,
+                  out_scale: Optional[str] = None, cite="") -> Optional[TRef]:
+        """residual + [out_scale *] fc2(act(fc1(LayerNormalization(x)))) as ONE launch (tfimm_hip_mlp_fused: the 4C-wide hidden
+        tensor stays in registers).  ``fc1`` / ``fc2`` are layer prefixes (kernel + bias).  Returns None when the shape is
+        not one the kernel is built for (C = 128, hidden = 512) -- the caller lowers the two GEMMs."""
+        if self.fp32 or os.environ.get("TFIMM_NO_MLP_FUSION"):
+            return None
+        k1, k2 = self.wget(fc1 + "/kernel"), self.wget(fc2 + "/kernel")
+        if k1.ndim == 4:     # ConvMLP: 1x1 convolutions (layers/transformers.py:238-252)
+            k1, k2 = k1[0, 0], k2[0, 0]
+        c, hid = k1.shape
+        if x.C != c or c != 128 or hid != 4 * c or k2.shape != (hid, c) or x.itemsize != 2:
+            return None
+        residual = x if residual is None else residual
+        assert residual.C == c and residual.rows == x.rows
+        p = self.p
+        gam, bet = self.wget(ln_prefix + "/gamma"), self.wget(ln_prefix + "/beta")
+        w1, b1, w2, b2 = pack.pack_mlp_fused(k1, self.wget(fc1 + "/bias"), gam, bet, k2, self.wget(fc2 + "/bias"),
+                                                 None if out_scale is None else self.wget(out_scale))
+        consts = {"w1": p.new_const(w1, fc1 + ":mlp_w1"), "b1": p.new_const(b1, fc1 + ":mlp_b1"), "w2": p.new_const(w2, fc2 + ":mlp_w2"),
+                  "b2": p.new_const(b2, fc2 + ":mlp_b2")}
+        out = p.new_tensor(x.rows, c, x.H, x.W, name=fc2 + ":mlp")
+        p.add("mlp_fused", [x, residual], out, consts, cite=cite, rows=x.rows, C=c, hidden=hid, act=act, eps=float(eps),
+              flops=4 * x.rows * c * hid)
+        return out
 
     def row_stats(self, x: TRef, eps: float, cite="") -> TRef:
         """(mean, rstd) of every row of x -- the statistics of a LayerNormalization that is folded into its consumers."""
@@ -1046,6 +1072,14 @@ class Plan:
                 d.act1, d.act2 = ffi.ACT[a["act1"]], ffi.ACT[a["act2"]]
                 self._keepalive.append(d)
                 self.calls.append((lib.tfimm_hip_conv_chain, (C.byref(d),)))
+            elif k == "mlp_fused":
+                d = ffi.MlpDesc()
+                d.x, d.residual, d.out = self.tptr(op.inputs[0]), self.tptr(op.inputs[1]), self.tptr(op.output)
+                d.w1, d.b1 = self.cptr(op.consts["w1"]), self.cptr(op.consts["b1"])
+                d.w2, d.b2 = self.cptr(op.consts["w2"]), self.cptr(op.consts["b2"])
+                d.M, d.C, d.hidden, d.act, d.eps = B * a["rows"], a["C"], a["hidden"], ffi.ACT[a["act"]], a["eps"]
+                self._keepalive.append(d)
+                self.calls.append((lib.tfimm_hip_mlp_fused, (C.byref(d),)))
             elif k == "expand_dwconv":
                 d = ffi.ExpandDwDesc()
                 d.x, d.y = self.tptr(op.inputs[0]), self.tptr(op.output)

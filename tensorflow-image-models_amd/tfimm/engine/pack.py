@@ -136,6 +136,26 @@ def chain_k_order(c1: int) -> np.ndarray:
     return (np.arange(0, c1, 16)[:, None] + inner[None, :]).reshape(-1)
 
 
+def pack_mlp_fused(k1: np.ndarray, b1: Optional[np.ndarray], gamma: np.ndarray, beta: np.ndarray, k2: np.ndarray,
+                   b2: Optional[np.ndarray], out_scale: Optional[np.ndarray] = None):
+    """Operands of tfimm_hip_mlp_fused for LayerNorm(gamma, beta) -> Dense k1 (C, H) + b1 -> act -> Dense k2 (H, C) + b2
+    (-> * out_scale): (w1 uint16 [H][C] with gamma folded, b1' f32 [H] = beta . k1 + b1, w2 uint16 [C][H] with its K axis
+    in chain_k_order and out_scale folded, b2' f32 [C])."""
+    c, h = k1.shape
+    assert k2.shape == (h, c) and gamma.shape == (c,) and beta.shape == (c,)
+    k1d = k1.astype(np.float64)
+    shift = beta.astype(np.float64) @ k1d
+    b1f = (shift if b1 is None else shift + b1.astype(np.float64)).astype(np.float32)
+    w1, _ = pack_dense((k1d * gamma.astype(np.float64).reshape(c, 1)).astype(np.float32), None)
+    k2d = k2.astype(np.float64)
+    b2d = np.zeros(c, np.float64) if b2 is None else b2.astype(np.float64)
+    if out_scale is not None:
+        g = out_scale.astype(np.float64).reshape(c)
+        k2d, b2d = k2d * g.reshape(1, c), b2d * g
+    w2, _ = pack_dense(k2d[chain_k_order(h)].astype(np.float32), None)
+    return (np.ascontiguousarray(w1[:h, :c]), b1f, np.ascontiguousarray(w2[:c, :h]), b2d.astype(np.float32))
+
+
 def pack_grouped3x3(kernel: np.ndarray, groups: int, scale: Optional[np.ndarray]) -> np.ndarray:
     """Grouped 3x3 kernel (3, 3, C / groups, C), input and output width of a group equal and <= 32 -> the per-lane MFMA A
     fragments tfimm_hip_grouped_conv3x3 keeps in registers: uint16 [C / 32][18][64][8].  Super-group sg = output channels

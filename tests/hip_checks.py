@@ -1204,6 +1204,51 @@ CASES["chain_shortcut_conv_multiround_b40"] = lambda: _chain_ds_case(40, 56, 56,
 CASES["chain_shortcut_conv_n512"] = lambda: _chain_ds_case(3, 14, 14, 512, 193)
 
 
+# ---------------------------------------------------------------------------------------------
+# fused transformer MLP (csrc/mlp.hip): LayerNorm -> fc1 -> act -> fc2 (-> LayerScale) -> + residual, hidden tensor in registers
+# ---------------------------------------------------------------------------------------------
+def _mlp_fused_case(M, seed, act="gelu", residual_is_x=True, layer_scale=False, x_offset=0.0):
+    import hip_ops as H
+    r = _rng(seed)
+    Cc, Hd, eps = 128, 512, 1e-5
+    x = _bf(r.standard_normal((M, Cc)) * r.uniform(0.2, 3.0, (M, 1)) + x_offset)
+    gam, bet = r.uniform(0.5, 1.5, Cc).astype(np.float32), (0.3 * r.standard_normal(Cc)).astype(np.float32)
+    k1 = (r.standard_normal((Cc, Hd)) / math.sqrt(Cc)).astype(np.float32)
+    b1 = (0.2 * r.standard_normal(Hd)).astype(np.float32)
+    k2 = (r.standard_normal((Hd, Cc)) / math.sqrt(Hd)).astype(np.float32)
+    b2 = (0.2 * r.standard_normal(Cc)).astype(np.float32)
+    ls = r.uniform(0.1, 1.0, Cc).astype(np.float32) if layer_scale else None
+    res = x if residual_is_x else _bf(r.standard_normal((M, Cc)))
+    w1, b1f, w2, b2f = pack.pack_mlp_fused(k1, b1, gam, bet, k2, b2, ls)
+    # reference: the layer's own definition in fp64, on the bf16-rounded folded weights the launch multiplies with (the normalised
+    # rows and the hidden activations are rounded to bf16 inside the launch: that is what the tolerance covers)
+    xd = x.astype(np.float64)
+    mean = xd.mean(axis=1, keepdims=True)
+    var = ((xd - mean) ** 2).mean(axis=1, keepdims=True)
+    w1r = pack.bf16_bits_to_f32(w1).astype(np.float64)                     # [Hd][C], gamma folded
+    hpre = ((xd - mean) / np.sqrt(var + eps)) @ w1r.T + b1f.astype(np.float64)
+    hact = _bf(O.activation(torch.from_numpy(hpre), act).numpy().astype(np.float32)).astype(np.float64)
+    order = pack.chain_k_order(Hd)
+    w2r = np.zeros((Cc, Hd))
+    w2r[:, order] = pack.bf16_bits_to_f32(w2).astype(np.float64)           # undo the K permutation
+    y = hact @ w2r.T + b2f.astype(np.float64) + res.astype(np.float64)
+    got = H.mlp_fused(H.dev_bf16(x), H.dev_bits(w1), H.dev_f32(b1f), H.dev_bits(w2), H.dev_f32(b2f),
+                      None if residual_is_x else H.dev_bf16(res), eps=eps, act=act)
+    H.sync()
+    return _err(_cpu(got), y), TOL_BF16
+
+
+CASES["mlp_fused_one_tile"] = lambda: _mlp_fused_case(256, 300)
+CASES["mlp_fused_ragged_77"] = lambda: _mlp_fused_case(77, 301)                                   # one partial tile
+CASES["mlp_fused_ragged_3000"] = lambda: _mlp_fused_case(3000, 302, residual_is_x=False)          # 12 tiles, last one ragged
+CASES["mlp_fused_multiround_70001"] = lambda: _mlp_fused_case(70001, 303)                         # 274 tiles: two rounds on some CUs
+CASES["mlp_fused_layerscale_residual"] = lambda: _mlp_fused_case(3136 * 3, 304, residual_is_x=False, layer_scale=True)   # ConvNeXt block
+CASES["mlp_fused_relu"] = lambda: _mlp_fused_case(1000, 305, act="relu")
+CASES["mlp_fused_swish"] = lambda: _mlp_fused_case(1000, 306, act="swish")
+CASES["mlp_fused_large_mean"] = lambda: _mlp_fused_case(2048, 307, x_offset=20.0)                 # mean >> spread: the c1 correction cancels
+CASES["mlp_fused_swin_stage1_b8"] = lambda: _mlp_fused_case(8 * 3136, 308)
+
+
 def _grouped_case(B, Hh, Ww, Cc, groups, stride, seed, act="relu"):
     import hip_ops as H
     r = _rng(seed)

@@ -332,6 +332,17 @@ def conv_chain(x, wt1, b1, wt2, b2, residual, *, KH, KW, stride, pad, OH, OW, C1
     return out
 
 
+def mlp_fused(x, w1, b1, w2, b2, residual=None, *, eps=1e-5, act="gelu"):
+    M, Cc = x.shape
+    d = ffi.MlpDesc()
+    out = torch.empty(M, Cc, dtype=torch.bfloat16, device=DEV)
+    d.x, d.w1, d.b1, d.w2, d.b2, d.out = ptr(x), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(out)
+    d.residual = ptr(x if residual is None else residual)
+    d.M, d.C, d.hidden, d.act, d.eps = M, Cc, w1.shape[0], ffi.ACT[act], eps
+    ffi.check(lib.tfimm_hip_mlp_fused(C.byref(d), stream()), "mlp_fused")
+    return out
+
+
 def grouped_conv3x3(x, wfrag, bias, stride, act=""):
     B, H, W, Cc = x.shape
     OH, OW = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1

@@ -269,3 +269,38 @@ def test_three_way_bf16_split_is_exact_to_24_bits():
     v = np.random.default_rng(0).standard_normal(1000).astype(np.float32) * np.float32(37.0)
     t = pack.bf16_bits_to_f32(pack.split3_bf16(v)).astype(np.float64)
     assert np.abs(t.sum(-1) - v.astype(np.float64)).max() <= np.abs(v).max() * 2.0 ** -23
+
+
+def test_narrow_mlp_blocks_are_one_launch(monkeypatch):
+    """Swin-B / ConvNeXt-B stage 1 (C = 128, hidden = 512): norm -> fc1 -> GELU -> fc2 -> + shortcut is one mlp_fused op; wider
+    stages keep the two GEMMs; the switch and the fp32 path lower the plain layers; the flop count does not change."""
+    kinds, prog = _kinds("swin_base_patch4_window7_224")
+    fused = [op for op in prog.ops if op.kind == "mlp_fused"]
+    assert len(fused) == 2 and all(op.attrs["rows"] == 3136 and op.inputs[0] == op.inputs[1] for op in fused)
+    flops = prog.flops_per_image()
+    kinds, prog = _kinds("convnext_base")
+    fused = [op for op in prog.ops if op.kind == "mlp_fused"]
+    assert len(fused) == 3 and all(op.inputs[0] != op.inputs[1] for op in fused)      # the shortcut is the block input
+    kinds, _ = _kinds("swin_tiny_patch4_window7_224")                                 # C = 96
+    assert "mlp_fused" not in kinds
+    monkeypatch.setenv("TFIMM_NO_MLP_FUSION", "1")
+    kinds, prog = _kinds("swin_base_patch4_window7_224")
+    assert "mlp_fused" not in kinds and prog.flops_per_image() == flops
+
+
+def test_mlp_fused_operands():
+    import numpy as np
+    from tfimm.engine import pack
+    r = np.random.default_rng(5)
+    c, h = 128, 512
+    k1, k2 = r.standard_normal((c, h)).astype(np.float32), r.standard_normal((h, c)).astype(np.float32)
+    b1, b2 = r.standard_normal(h).astype(np.float32), r.standard_normal(c).astype(np.float32)
+    gam, bet, ls = (r.standard_normal(c).astype(np.float32) for _ in range(3))
+    w1, b1f, w2, b2f = pack.pack_mlp_fused(k1, b1, gam, bet, k2, b2, ls)
+    assert w1.shape == (h, c) and w2.shape == (c, h) and w1.dtype == w2.dtype == np.uint16
+    np.testing.assert_allclose(pack.bf16_bits_to_f32(w1), (k1 * gam[:, None]).T, rtol=2 ** -8)
+    np.testing.assert_allclose(b1f, bet.astype(np.float64) @ k1 + b1, rtol=1e-5, atol=1e-5)
+    order = pack.chain_k_order(h)
+    assert sorted(order) == list(range(h))
+    np.testing.assert_allclose(pack.bf16_bits_to_f32(w2), ((k2 * ls[None, :])[order]).T, rtol=2 ** -8)
+    np.testing.assert_allclose(b2f, b2 * ls, rtol=1e-6)

@@ -60,6 +60,10 @@ def op_bytes_flops(op, prog, B):
         return byts, float(a["flops"]) * B, (f"M={M} 3x3 {a['Cin']}->{a['C1']} -> 1x1 ->{a['N2']}" +
                                              (" +res" if a.get("has_residual") else "") +
                                              (" +shortcut conv" if a.get("has_ds") else "") + " (fused bottleneck tail)")
+    if k == "mlp_fused":
+        M = B * a["rows"]
+        byts = M * a["C"] * 2 * (3 if op.inputs[0] != op.inputs[1] else 2) + 2 * a["C"] * a["hidden"] * 2
+        return byts, float(a["flops"]) * B, f"M={M} LN -> {a['C']}->{a['hidden']} {a['act']} -> {a['C']} +res (fused MLP)"
     if k == "expand_dwconv":
         byts = B * (a["H"] * a["W"] * a["Cin"] + a["OH"] * a["OW"] * a["C"]) * 2
         return byts, float(a["flops"]) * B, f"{a['Cin']}->{a['C']} k={a['k']} s={a['stride']} {a['H']}->{a['OH']} (fused expand + dw)"

@@ -1,0 +1,62 @@
+// Where the cycles of tfimm_hip_mlp_fused go: compiles csrc/mlp.hip with MLP_STAMPS (s_memtime of workgroup 0, waves 0 and 4,
+// before every step's wait and after its barrier + DMA requests) and prints, per slot of a steady-state tile, the cycles
+// a wave spent IN its step (GEMM / activation / epilogue) and the cycles it spent waiting for pieces and for the barrier.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DMLP_STAMPS -Iinclude -Itensorflow-image-models_amd/csrc \
+//         tools/probes/mlp_stamps_probe.hip -o /tmp/mlp_probe && /tmp/mlp_probe [rows]
+#include "../../tensorflow-image-models_amd/csrc/mlp.hip"
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+static char g_err[512];
+void tfimm_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap); }
+
+int main(int argc, char** argv) {
+  const long long M = argc > 1 ? atoll(argv[1]) : 802816;
+  const int C = 128, H = 512;
+  std::vector<unsigned short> hx((size_t)M * C), hw1((size_t)H * C), hw2((size_t)C * H);
+  std::vector<float> hb1(H, 0.1f), hb2(C, 0.2f);
+  unsigned s = 12345u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (unsigned short)(0x3f00u + ((s >> 16) & 0xffu) + ((s >> 9) & 0x8000u)); };
+  for (auto& v : hx) v = rnd();
+  for (auto& v : hw1) v = (unsigned short)(rnd() - 0x0300u);
+  for (auto& v : hw2) v = (unsigned short)(rnd() - 0x0380u);
+  void *x, *w1, *w2, *out; float *b1, *b2; long long* st;
+  hipMalloc(&x, hx.size() * 2); hipMalloc(&out, hx.size() * 2); hipMalloc(&w1, hw1.size() * 2); hipMalloc(&w2, hw2.size() * 2);
+  hipMalloc(&b1, H * 4); hipMalloc(&b2, C * 4); hipMalloc(&st, 4096 * 8);
+  hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice); hipMemcpy(w1, hw1.data(), hw1.size() * 2, hipMemcpyHostToDevice);
+  hipMemcpy(w2, hw2.data(), hw2.size() * 2, hipMemcpyHostToDevice); hipMemcpy(b1, hb1.data(), H * 4, hipMemcpyHostToDevice);
+  hipMemcpy(b2, hb2.data(), C * 4, hipMemcpyHostToDevice); hipMemset(st, 0, 4096 * 8);
+  tfimm_mlp_stamps = st;
+  tfimm_mlp_desc d{};
+  d.x = x; d.w1 = w1; d.b1 = b1; d.w2 = w2; d.b2 = b2; d.residual = x; d.out = out; d.M = M; d.C = C; d.hidden = H;
+  d.act = TFIMM_ACT_GELU; d.eps = 1e-5f;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int it = 0; it < 3; ++it) {
+    hipEventRecord(e0, 0);
+    if (tfimm_hip_mlp_fused(&d, nullptr) != 0) { printf("launch failed: %s\n", g_err); return 1; }
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    printf("run %d: %.1f us  (%.1f TFLOP/s)\n", it, ms * 1e3, 4.0 * M * C * H / (ms * 1e-3) / 1e12);
+  }
+  std::vector<long long> h(4096);
+  hipMemcpy(h.data(), st, 4096 * 8, hipMemcpyDeviceToHost);
+  // stamps per step: [before wait, after barrier + requests]; a tile is 18 steps (hi: + 1 leading duty-only sync)
+  for (int half = 0; half < 2; ++half) {
+    const long long* t = h.data() + half * 2048;
+    const int lead = half ? 2 : 0;                   // the hi waves' extra sync
+    const int tile = 1;                              // second tile of the workgroup: steady state
+    const int base = lead + tile * 36;
+    printf("%s wave, tile %d: step  in-step  wait+barrier  (cycles)\n", half ? "hi" : "lo", tile);
+    long long sum_step = 0, sum_wait = 0;
+    for (int i = 0; i < 18; ++i) {
+      const long long wait = t[base + 2 * i + 1] - t[base + 2 * i];
+      const long long step = t[base + 2 * i + 2] - t[base + 2 * i + 1];
+      printf("  %2d  %7lld  %7lld\n", i, step, wait);
+      sum_step += step; sum_wait += wait;
+    }
+    printf("  tile total %lld cycles: %lld in steps, %lld waiting\n", t[base + 36] - t[base], sum_step, sum_wait);
+  }
+  return 0;
+}
