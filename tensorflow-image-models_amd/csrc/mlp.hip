@@ -16,21 +16,16 @@
 //     and those packed accumulators ARE the B operand of GEMM 2 (one row per lane, 8 consecutive k per lane up to the
 //     order of the k values, which the host bakes into W2: pack.chain_k_order, the register chain of
 //     gemm_chain_kernel.h), 16 more MFMAs into the 32 x 128 output accumulators that live across all 8 groups;
-//   * the two waves of a SIMD (w and w + 4) run HALF A GROUP OUT OF PHASE: time is cut into slots separated by workgroup
-//     barriers; in every slot one of them multiplies (M: GEMM 2 of group g + GEMM 1 of group g + 1, 32 MFMAs, hand-scheduled
-//     with its LDS fragment reads) while the other runs the activation (V: ~10 VALU instructions per hidden element), so
-//     the matrix pipe and the vector ALU of the SIMD are both busy.  (One launch-wide phase: both waves would multiply,
-//     then both would sit in the VALU with the matrix pipe idle -- the activation costs more cycles than the MFMAs.)
-//   * epilogue: + b2 + residual rows, bf16, 8-byte row segments straight from the accumulator layout.
+//   * all eight waves walk the groups in step (one workgroup barrier per group: the ring stage of group g + 1 is requested
+//     behind it).  The two waves of a SIMD are in the SAME phase on purpose: measured on gfx950
+//     (tools/probes/valu_mfma_overlap_probe.hip, profiles/r03_valu_mfma_overlap_probe.txt) a wave's v_pk_fma_f32 stream
+//     runs at 8.5 cycles per instruction alone, 4.5 when the OTHER wave of the SIMD is in the VALU too, and 24.5 when
+//     the other wave issues back-to-back MFMAs (whose rate does not change) -- a matrix instruction's operand reads go
+//     through the vector register ports.  A variant with the two waves half a group out of phase (one multiplies while
+//     the other runs the activation) was 2.2x SLOWER per tile than this one (profiles/r03_mlp_pingpong_stamps.txt);
+//   * the output accumulators START as residual + b2 (the residual rows are requested at the top of the tile and
+//     unpacked just before the first GEMM 2: their latency is behind a whole group of work), so the epilogue is 16 stores.
 // The intermediate is rounded to bf16 exactly once, like the two-launch path rounds the tensor it stores.
-//
-// Slots of a tile (lo = waves 0-3, hi = waves 4-7; NG = 8 groups):
-//     slot 0      lo: normalise, GEMM1(0)          hi: epilogue of the previous tile, normalise
-//     slot 1      lo: V(0)                         hi: GEMM1(0)
-//     slot 2g+2   lo: GEMM2(g) + GEMM1(g+1)        hi: V(g)
-//     slot 2g+3   lo: V(g+1)  (g = 7: epilogue)    hi: GEMM2(g) + GEMM1(g+1)
-// Weight DMA (every wave its pieces, after the slot's barrier): slot 2k brings W1(k+1) and W2(k), both first read in slot
-// 2k + 2 and last read in slot 2k + 3 -- two ring stages each.  The x rows of the next tile are requested in slot 1.
 #include "gemm_stream_kernel.h"
 
 using namespace tfimm_gemm;
@@ -46,6 +41,7 @@ struct MlpArgs {
   const bf16_t* residual;   // [M][C]
   bf16_t* out;              // [M][C]
   int M, act;
+  int res_is_x;             // the shortcut is x itself: its rows are taken from the x tile in LDS
   float eps;
   unsigned x_bytes, w1_bytes, w2_bytes, b1_bytes, b2_bytes, out_bytes;
   int n_tiles;
@@ -62,7 +58,10 @@ struct MlpGeom {
   static constexpr int W1_BYTES = HG * C * 2, W2_BYTES = C * HG * 2;
   static constexpr int TAB_BYTES = 3072;                   // b1 [4C] fp32 (2 KiB) | b2 [C] fp32 in a 1-KiB piece
   static constexpr int OFF_W1 = X_BYTES, OFF_W2 = OFF_W1 + 2 * W1_BYTES, OFF_TAB = OFF_W2 + 2 * W2_BYTES;
-  static constexpr int LDS_BYTES = OFF_TAB + TAB_BYTES;
+  static constexpr int STG_PITCH = 80;                     // staging rows of the output transpose: 64 bytes + 16 of padding
+  static constexpr int STG_BYTES = 32 * STG_PITCH;         // per wave: 32 rows x 32 channels
+  static constexpr int OFF_STG = OFF_TAB + TAB_BYTES;
+  static constexpr int LDS_BYTES = OFF_STG + NW * STG_BYTES;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -139,8 +138,7 @@ __global__ void __launch_bounds__(512) mlp_fused_kernel(const MlpArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool hi = wave >= 4;           // waves w and w + 4 share a SIMD: the hi one runs a slot behind
-  const int frow = lane & 31, fhi = lane >> 5;
+    const int frow = lane & 31, fhi = lane >> 5;
 
   int t_first, t_hi, t_step;
   {
@@ -260,35 +258,84 @@ __global__ void __launch_bounds__(512) mlp_fused_kernel(const MlpArgs p) {
       }
     }
   };
-  // + b2 + residual, bf16, 8 bytes per lane and accumulator quad (row frow, channels b*32 + q*8 + fhi*4 ..)
-  auto epilogue = [&](int m0) __attribute__((always_inline)) {
-    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+  // residual rows of this wave in the accumulator layout: 8 bytes per lane and accumulator quad (row frow, channels
+  // b*32 + q*8 + fhi*4 ..), requested at the top of a tile ...
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+  u32x2 rr[NB2 * 4];
+  auto row_offset = [&](int m0) __attribute__((always_inline)) {
     const int m = m0 + wave * 32 + frow;
-    const unsigned rowoff = (m < p.M) ? (unsigned)((size_t)m * C * 2) : kOobOffset;
+    return (m < p.M) ? (unsigned)((size_t)m * C * 2) + (unsigned)(fhi * 8) : kOobOffset;
+  };
+  auto request_residual = [&](int m0) __attribute__((always_inline)) {
+    if (p.res_is_x) {
+      // chunk cc = 4 b + q of this lane's row, its half fhi: address = ar ^ (cc << 4) (the row swizzle is an XOR on the chunk bits)
+      const unsigned ar = opaque((unsigned)(size_t)(lds_ptr_t)(sX + (wave * 32 + frow) * 256 + ((frow & 15) << 4) + fhi * 8));
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        unsigned a[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = ar ^ (unsigned)((h * 8 + i) << 4);
+        asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %9\n\tds_read_b64 %2, %10\n\tds_read_b64 %3, %11\n\t"
+                     "ds_read_b64 %4, %12\n\tds_read_b64 %5, %13\n\tds_read_b64 %6, %14\n\tds_read_b64 %7, %15\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(rr[h * 8 + 0]), "=&v"(rr[h * 8 + 1]), "=&v"(rr[h * 8 + 2]), "=&v"(rr[h * 8 + 3]), "=&v"(rr[h * 8 + 4]),
+                       "=&v"(rr[h * 8 + 5]), "=&v"(rr[h * 8 + 6]), "=&v"(rr[h * 8 + 7])
+                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");
+      }
+      return;
+    }
+    const unsigned rowoff = row_offset(m0);
+#pragma unroll
+    for (int i = 0; i < NB2 * 4; ++i)
+      rr[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_r, (int)(rowoff == kOobOffset ? kOobOffset : rowoff + (unsigned)(i * 16)), 0, 0));
+  };
+  // ... and turned into the initial value of the output accumulators, + b2, just before the first GEMM 2
+  auto init_acc2 = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int b = 0; b < NB2; ++b) {
       mlp_u32x4 tb[4];
-      const unsigned ta = tab_addr + 2048u + (unsigned)((b * 32 + fhi * 4) * 4);
+      const unsigned ta = opaque(tab_addr) + 2048u + (unsigned)((b * 32 + fhi * 4) * 4);
       asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\t"
                    "ds_read_b128 %3, %4 offset:96\n\ts_waitcnt lgkmcnt(0)"
                    : "=&v"(tb[0]), "=&v"(tb[1]), "=&v"(tb[2]), "=&v"(tb[3]) : "v"(ta) : "memory");
-      u32x2 rr[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const unsigned off = rowoff == kOobOffset ? kOobOffset : rowoff + (unsigned)(b * 32 + q * 8 + fhi * 4) * 2u;
-        rr[q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc_r, (int)off, 0, 0));
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const unsigned off = rowoff == kOobOffset ? kOobOffset : rowoff + (unsigned)(b * 32 + q * 8 + fhi * 4) * 2u;
         const float4 b4 = __builtin_bit_cast(float4, tb[q]);
-        const float r0 = __uint_as_float(rr[q][0] << 16), r1 = __uint_as_float(rr[q][0] & 0xffff0000u);
-        const float r2 = __uint_as_float(rr[q][1] << 16), r3 = __uint_as_float(rr[q][1] & 0xffff0000u);
-        u32x2 o;
-        o[0] = pack_bf2(acc2[b][q * 4 + 0] + b4.x + r0, acc2[b][q * 4 + 1] + b4.y + r1);
-        o[1] = pack_bf2(acc2[b][q * 4 + 2] + b4.z + r2, acc2[b][q * 4 + 3] + b4.w + r3);
-        __builtin_amdgcn_raw_buffer_store_b64(o, rsrc_o, (int)off, 0, 0);
+        const u32x2 r = rr[b * 4 + q];
+        acc2[b][q * 4 + 0] = __uint_as_float(r[0] << 16) + b4.x;
+        acc2[b][q * 4 + 1] = __uint_as_float(r[0] & 0xffff0000u) + b4.y;
+        acc2[b][q * 4 + 2] = __uint_as_float(r[1] << 16) + b4.z;
+        acc2[b][q * 4 + 3] = __uint_as_float(r[1] & 0xffff0000u) + b4.w;
       }
+    }
+  };
+  // Output: one row per lane in the accumulators, 16-byte row segments in HBM -- transposed through a wave-private staging
+  // block, 32 channels (one accumulator block) at a time: 4 x (4 ds_write_b64, 2 ds_read_b128, 2 stores of 16 bytes; a store
+  // instruction covers 64 contiguous bytes of 16 rows -- straight from the accumulator layout it would be 8 bytes of 64 rows,
+  // and 16 such stores per lane took ~5700 cycles of a ~73000-cycle tile).  All LDS traffic is explicit: the next tile's
+  // weights are in flight, and in front of an LDS access it can see hipcc waits for every outstanding DMA.
+  auto store_tile = [&](int m0) __attribute__((always_inline)) {
+    const unsigned stg = opaque((unsigned)(size_t)(lds_ptr_t)(smem + G::OFF_STG + wave * G::STG_BYTES));
+    const unsigned wa = stg + (unsigned)(frow * G::STG_PITCH + fhi * 8);                  // + q * 16
+    const unsigned ra = stg + (unsigned)((lane >> 2) * G::STG_PITCH + (lane & 3) * 16);   // + 16 rows for the second read
+    const int mrow = m0 + wave * 32 + (lane >> 2);
+    const unsigned o0 = (mrow < p.M) ? (unsigned)((size_t)mrow * C * 2) + (unsigned)((lane & 3) * 16) : kOobOffset;
+    const unsigned o1 = (mrow + 16 < p.M) ? (unsigned)((size_t)(mrow + 16) * C * 2) + (unsigned)((lane & 3) * 16) : kOobOffset;
+#pragma unroll
+    for (int b = 0; b < NB2; ++b) {
+      u32x2 o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        o[q][0] = pack_bf2(acc2[b][q * 4 + 0], acc2[b][q * 4 + 1]);
+        o[q][1] = pack_bf2(acc2[b][q * 4 + 2], acc2[b][q * 4 + 3]);
+      }
+      mlp_u32x4 v0, v1;
+      asm volatile("ds_write_b64 %2, %4\n\tds_write_b64 %2, %5 offset:16\n\tds_write_b64 %2, %6 offset:32\n\t"
+                   "ds_write_b64 %2, %7 offset:48\n\ts_waitcnt lgkmcnt(0)\n\t"
+                   "ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1280\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(v0), "=&v"(v1) : "v"(wa), "v"(ra), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]) : "memory");
+      __builtin_amdgcn_raw_buffer_store_b128(v0, rsrc_o, (int)(o0 == kOobOffset ? kOobOffset : o0 + (unsigned)(b * 64)), 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(v1, rsrc_o, (int)(o1 == kOobOffset ? kOobOffset : o1 + (unsigned)(b * 64)), 0, 0);
     }
   };
   // this wave's rows out of the x tile, normalised: xhat = (x - mean) * rstd in bf16 = the B fragments of GEMM 1
@@ -350,86 +397,66 @@ __global__ void __launch_bounds__(512) mlp_fused_kernel(const MlpArgs p) {
   }
   issue_x(t_first, true);
   issue_w1(0, 0, true);
+  issue_w2(0, 0, true);
 
-  // ---- slot duties.  Global slot T of a tile (T = 0 .. 17; the lo waves run step T in it, the hi waves step T - 1 -- the hi
-  // waves pass one extra barrier before their first step and run the SAME code one slot late; s_barrier counts arrivals,
-  // not program counters).  Before a slot's barrier every wave waits for ITS pieces of what the slot's readers need, after
-  // it it requests its pieces of
-  //     T = 0     needs x(tile), W1(0)          requests W1(1), W2(0)
-  //     T = 2k    needs W1(k), W2(k-1)          requests W1(k+1) (k = 7: the next tile's W1(0)), W2(k); T = 2 also x(next tile):
-  //                                             lo normalised in slot 0, hi in slot 1
-  // (first read two slots later by lo, three by hi; last read one / two slots before the stage is requested again).
-  // Counted waits: newer than the pieces a slot needs are only a wave's own epilogue traffic (16 loads + 16 stores; lo: slot
-  // 17, hi: slot 0 behind its requests) and, in slot 4, the 8 x pieces requested behind W1(2) / W2(1).
-  const int hi_i = hi ? 1 : 0;
 #ifdef MLP_STAMPS
   int n_stamp = 0;
 #define MLP_STAMP()                                                                                  \
   do {                                                                                               \
     if (blockIdx.x == 0 && (wave & 3) == 0 && n_stamp < 2048) {                                      \
       const long long t_ = (long long)__builtin_amdgcn_s_memtime();                                  \
-      if (lane == 0) p.stamps[hi_i * 2048 + n_stamp] = t_;                                           \
+      if (lane == 0) p.stamps[(wave >> 2) * 2048 + n_stamp] = t_;                                    \
       ++n_stamp;                                                                                     \
     }                                                                                                \
   } while (0)
 #else
 #define MLP_STAMP() do {} while (0)
 #endif
+
+  // Requests and waits (every wave ITS pieces; the barrier makes them everyone's): the barrier of group g stands behind the last
+  // read of ring stage (g + 1) & 1 (group g - 1) and in front of the first read of stage g & 1:
+  //     behind barrier g:   W1(g+1), W2(g+1) -> stage (g + 1) & 1   (g = NG - 1: the next tile's group 0);   g = 1: also the next
+  //                         tile's x rows (every wave normalised its rows before that barrier)
+  //     before barrier g:   this wave's pieces of group g have landed.  Newer than them are only the 8 x pieces (g = 2) and,
+  //                         at the top of a tile, the 8 stores of the previous tile
   bool first_tile = true;
-  int duty_tile = t_first;             // the tile whose slots the duties of this wave are in (hi: one slot ahead of its steps)
-  auto sync = [&](int i) __attribute__((always_inline)) {
-    int T = i + hi_i;
-    if (T == 2 * NG + 2) {               // a hi wave's last step of a tile runs in slot 0 of the next tile
-      T = 0;
-      duty_tile += t_step;
-      first_tile = false;
-      if (duty_tile >= t_hi) { MLP_STAMP(); MLP_STAMP(); return; }     // no next tile: nothing to wait for, nobody to meet
-    }
-    MLP_STAMP();
-    const bool next_exists = duty_tile + t_step < t_hi;
-    if ((T & 1) == 0) {
-      const int k = T >> 1;
-      if (k == 0) {
-        if (!hi && !first_tile) MLP_WAIT(16); else MLP_WAIT(0);
-      } else if (k == 1) {
-        if (hi && !first_tile) MLP_WAIT(16); else MLP_WAIT(0);
-      } else if (k == 2) {
+  for (int tile = t_first; tile < t_hi; tile += t_step) {
+    const int m0 = tile * BM;
+    const bool has_next = tile + t_step < t_hi;
+#pragma unroll 1
+    for (int g = 0; g < NG; ++g) {
+      MLP_STAMP();
+      if (g == 0) {
+        if (first_tile) MLP_WAIT(0); else MLP_WAIT(8);
+      } else if (g == 2) {
         MLP_WAIT(8);
       } else {
         MLP_WAIT(0);
       }
-    }
-    MLP_BARRIER();
-    if ((T & 1) == 0) {
-      const int k = T >> 1;
-      if (k + 1 < NG) issue_w1(k + 1, (k + 1) & 1, true);
-      else if (k + 1 == NG) issue_w1(0, 0, next_exists);
-      if (k < NG) issue_w2(k, k & 1, true);
-      if (k == 1) issue_x(duty_tile + t_step, next_exists);
+      MLP_BARRIER();
+      if (g + 1 < NG) {
+        issue_w1(g + 1, (g + 1) & 1, true);
+        issue_w2(g + 1, (g + 1) & 1, true);
+      } else {
+        issue_w1(0, 0, has_next);
+        issue_w2(0, 0, has_next);
+      }
+      if (g == 1) issue_x(tile + t_step, has_next);
+      MLP_STAMP();
+      if (g == 0) {
+        request_residual(m0);
+        normalise();
+      }
+      gemm1(g);
+      MLP_STAMP();
+      vstep(g);
+      MLP_STAMP();
+      if (g == 0) init_acc2();
+      gemm2(g);
     }
     MLP_STAMP();
-  };
-  if (hi) sync(-1);                      // slot 0 of the first tile: the hi waves only do their duties in it
-  for (int tile = t_first; tile < t_hi; tile += t_step) {
-    const int m0 = tile * BM;
-    // steps of a tile: 2g: [normalise] GEMM2(g-1), GEMM1(g);  2g+1: V(g) -- and the epilogue as step 2 NG + 1
-#pragma unroll 1
-    for (int g = 0; g <= NG; ++g) {
-      sync(2 * g);
-      if (g == 0) {
-#pragma unroll
-        for (int b = 0; b < NB2; ++b)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc2[b][e] = 0.f;
-        normalise();
-      } else {
-        gemm2(g - 1);
-      }
-      if (g < NG) gemm1(g);
-      sync(2 * g + 1);
-      if (g < NG) vstep(g); else epilogue(m0);
-    }
-    if (!hi) { duty_tile += t_step; first_tile = false; }
+    store_tile(m0);
+    first_tile = false;
   }
   MLP_WAIT(0);
 #undef MLP_WAIT
@@ -469,6 +496,7 @@ extern "C" int tfimm_hip_mlp_fused(const tfimm_mlp_desc* dp, void* stream) {
   a.x = (const bf16_t*)d.x; a.w1 = (const bf16_t*)d.w1; a.b1 = d.b1; a.w2 = (const bf16_t*)d.w2; a.b2 = d.b2;
   a.residual = (const bf16_t*)d.residual; a.out = (bf16_t*)d.out;
   a.M = (int)d.M; a.act = d.act; a.eps = d.eps;
+  a.res_is_x = d.residual == d.x;
   a.x_bytes = (unsigned)act_bytes; a.out_bytes = (unsigned)act_bytes;
   a.w1_bytes = (unsigned)((size_t)d.hidden * d.C * 2); a.w2_bytes = (unsigned)((size_t)d.C * d.hidden * 2);
   a.b1_bytes = (unsigned)(d.hidden * 4); a.b2_bytes = (unsigned)(d.C * 4);

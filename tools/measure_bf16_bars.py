@@ -54,9 +54,18 @@ def main():
     os.makedirs(out, exist_ok=True)
     json.dump(obs, open(os.path.join(out, "bf16_observed.json"), "w"), indent=1, sort_keys=True)
     if "--write-bars" in sys.argv:
-        bars = {n: {"logits": ceil2(2 * o["logits"]), "features": ceil2(2 * max(o["features"].values(), default=0.0)),
-                    "top1": bool(o["top1_agree"] == 1.0)} for n, o in obs.items()}
-        json.dump(bars, open(os.path.join(out, "bf16_bars.json"), "w"), indent=1, sort_keys=True)
+        # top-1 is only held where the reference's own margin is at least twice the observed logit error of that row: on the
+        # random-weight minis with near-tied logits an argmax agreement is luck, and a 1e-5 change of an activation flips it
+        bars = {n: {"logits_bar": ceil2(2 * o["logits"]), "features_bar": ceil2(2 * max(o["features"].values(), default=0.0)),
+                    "top1": bool(o["top1_agree"] == 1.0 and o["min_margin_over_row_err"] >= 2.0),
+                    "observed_logits": float(f"{o['logits']:.4g}"),
+                    "observed_features_max": float(f"{max(o['features'].values(), default=0.0):.4g}"),
+                    "observed_min_margin_over_row_err": float(f"{o['min_margin_over_row_err']:.3g}")} for n, o in obs.items()}
+        doc = ("bf16 product path vs the reference-code goldens (forward_golden.npz): observed rel-to-max error on an MI355X (the "
+               "forward is bit-reproducible, so these are exact) and the bars tests/test_golden.py holds it to = 2 x observed "
+               "(tools/measure_bf16_bars.py --write-bars; top1 only where the reference's margin is >= 2 x the row's error).  "
+               "Semantic exactness is the float32 path's job: tests/test_gpu_fp32.py, 1e-3.")
+        json.dump({"_doc": doc, "models": bars}, open(os.path.join(out, "bf16_bars.json"), "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

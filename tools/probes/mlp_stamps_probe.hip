@@ -1,6 +1,6 @@
 // Where the cycles of tfimm_hip_mlp_fused go: compiles csrc/mlp.hip with MLP_STAMPS (s_memtime of workgroup 0, waves 0 and 4,
-// before every step's wait and after its barrier + DMA requests) and prints, per slot of a steady-state tile, the cycles
-// a wave spent IN its step (GEMM / activation / epilogue) and the cycles it spent waiting for pieces and for the barrier.
+// at the top of every group, behind its barrier + DMA requests, behind GEMM 1 and behind the activation) and prints the
+// cycles of every part for a steady-state tile.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DMLP_STAMPS -Iinclude -Itensorflow-image-models_amd/csrc \
 //         tools/probes/mlp_stamps_probe.hip -o /tmp/mlp_probe && /tmp/mlp_probe [rows]
 #include "../../tensorflow-image-models_amd/csrc/mlp.hip"
@@ -42,21 +42,17 @@ int main(int argc, char** argv) {
   }
   std::vector<long long> h(4096);
   hipMemcpy(h.data(), st, 4096 * 8, hipMemcpyDeviceToHost);
-  // stamps per step: [before wait, after barrier + requests]; a tile is 18 steps (hi: + 1 leading duty-only sync)
+  // stamps per group: [top, behind barrier + requests, behind GEMM 1, behind the activation]; + one in front of the stores
   for (int half = 0; half < 2; ++half) {
     const long long* t = h.data() + half * 2048;
-    const int lead = half ? 2 : 0;                   // the hi waves' extra sync
-    const int tile = 1;                              // second tile of the workgroup: steady state
-    const int base = lead + tile * 36;
-    printf("%s wave, tile %d: step  in-step  wait+barrier  (cycles)\n", half ? "hi" : "lo", tile);
-    long long sum_step = 0, sum_wait = 0;
-    for (int i = 0; i < 18; ++i) {
-      const long long wait = t[base + 2 * i + 1] - t[base + 2 * i];
-      const long long step = t[base + 2 * i + 2] - t[base + 2 * i + 1];
-      printf("  %2d  %7lld  %7lld\n", i, step, wait);
-      sum_step += step; sum_wait += wait;
+    const int tile = 1, per_tile = 8 * 4 + 1;       // second tile of the workgroup: steady state
+    const int base = tile * per_tile;
+    printf("wave %d, tile %d: group  wait+barrier+requests  [normalise+]GEMM1  activation  GEMM2   (cycles)\n", half * 4, tile);
+    for (int g = 0; g < 8; ++g) {
+      const long long* q = t + base + 4 * g;
+      printf("  %d  %7lld  %7lld  %7lld  %7lld\n", g, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3]);
     }
-    printf("  tile total %lld cycles: %lld in steps, %lld waiting\n", t[base + 36] - t[base], sum_step, sum_wait);
+    printf("  stores %lld;  tile total %lld cycles\n", t[base + per_tile] - t[base + per_tile - 1], t[base + per_tile] - t[base]);
   }
   return 0;
 }
