@@ -77,6 +77,64 @@ __global__ void cast_rgb4_kernel(const void* in, uint2* out, int64_t n_pixels) {
   }
 }
 
+// bf16 RGB, FOUR pixels per thread: 24 contiguous input bytes as three 8-byte loads, 32 output bytes (the one-pixel kernels
+// issue three 2-byte loads per pixel and reach 2.3 - 2.9 TB/s on a copy that is pure HBM traffic)
+__device__ __forceinline__ void rgb4_quad(const uint2* src, uint2* o) {
+  const uint2 a = src[0], b = src[1], c = src[2];          // r0 g0 | b0 r1,  g1 b1 | r2 g2,  b2 r3 | g3 b3
+  o[0] = make_uint2(a.x, a.y & 0xffffu);
+  o[1] = make_uint2((a.y >> 16) | (b.x << 16), b.x >> 16);
+  o[2] = make_uint2(b.y, c.x & 0xffffu);
+  o[3] = make_uint2((c.x >> 16) | (c.y << 16), c.y >> 16);
+}
+__global__ void cast_rgb4_quad_kernel(const uint2* in, uint4* out, int64_t n_quads) {
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += (int64_t)gridDim.x * blockDim.x) {
+    uint2 o[4];
+    rgb4_quad(in + q * 3, o);
+    out[q * 2] = make_uint4(o[0].x, o[0].y, o[1].x, o[1].y);
+    out[q * 2 + 1] = make_uint4(o[2].x, o[2].y, o[3].x, o[3].y);
+  }
+}
+// the same into a zero-bordered image: one thread per quad of INTERIOR pixels (W % 4 == 0), the border by the threads behind
+__global__ void cast_pad4_quad_kernel(const uint2* in, uint2* out, int B, int H, int W, int pad_t, int pad_l, int HP, int WP) {
+  const int wq = W >> 2;
+  const int64_t n_quads = (int64_t)B * H * wq;
+  const int64_t n_border = (int64_t)B * ((int64_t)HP * WP - (int64_t)H * W);
+  const int border_row = WP - W;                            // border pixels of an interior row
+  const int64_t per_image = (int64_t)HP * WP - (int64_t)H * W;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n_quads + n_border; id += (int64_t)gridDim.x * blockDim.x) {
+    if (id < n_quads) {
+      const int xq = (int)(id % wq);
+      const int64_t t = id / wq;
+      const int y = (int)(t % H);
+      const int b = (int)(t / H);
+      uint2 o[4];
+      rgb4_quad(in + id * 3, o);
+      uint2* dst = out + ((int64_t)b * HP + (y + pad_t)) * WP + pad_l + xq * 4;
+      dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
+    } else {
+      int64_t r = id - n_quads;
+      const int b = (int)(r / per_image);
+      r -= (int64_t)b * per_image;
+      // border pixels of an image in order: pad_t full rows, then per interior row its left and right margins, then the rest
+      int yp, xp;
+      const int64_t top = (int64_t)pad_t * WP;
+      const int64_t mid = (int64_t)H * border_row;
+      if (r < top) {
+        yp = (int)(r / WP); xp = (int)(r % WP);
+      } else if (r < top + mid) {
+        const int64_t m = r - top;
+        const int row = (int)(m / border_row), k = (int)(m % border_row);
+        yp = pad_t + row;
+        xp = k < pad_l ? k : k + W;
+      } else {
+        const int64_t m = r - top - mid;
+        yp = pad_t + H + (int)(m / WP); xp = (int)(m % WP);
+      }
+      out[((int64_t)b * HP + yp) * WP + xp] = make_uint2(0u, 0u);
+    }
+  }
+}
+
 // image -> zero-bordered 4-channel bf16 image (one thread per OUTPUT pixel)
 template <bool IN_BF16>
 __global__ void cast_pad4_kernel(const void* in, uint2* out, int B, int H, int W, int c_in, int pad_t, int pad_l,
@@ -1163,8 +1221,13 @@ extern "C" int tfimm_hip_cast_input(const void* in, int in_dtype, void* out, int
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = grid_for(n_pixels, 256);
   if (c_in == 3 && c_out == 4 && (((uintptr_t)out & 7) == 0)) {
-    if (in_dtype) TFIMM_LAUNCH(cast_rgb4_kernel<true>, dim3(grid), dim3(256), 0, st, in, (uint2*)out, n_pixels);
-    else TFIMM_LAUNCH(cast_rgb4_kernel<false>, dim3(grid), dim3(256), 0, st, in, (uint2*)out, n_pixels);
+    if (in_dtype && (n_pixels & 3) == 0 && (((uintptr_t)in & 7) == 0) && (((uintptr_t)out & 15) == 0)) {
+      TFIMM_LAUNCH(cast_rgb4_quad_kernel, dim3(grid_for(n_pixels / 4, 256)), dim3(256), 0, st, (const uint2*)in, (uint4*)out, n_pixels / 4);
+    } else if (in_dtype) {
+      TFIMM_LAUNCH(cast_rgb4_kernel<true>, dim3(grid), dim3(256), 0, st, in, (uint2*)out, n_pixels);
+    } else {
+      TFIMM_LAUNCH(cast_rgb4_kernel<false>, dim3(grid), dim3(256), 0, st, in, (uint2*)out, n_pixels);
+    }
   } else {
     if (in_dtype) TFIMM_LAUNCH(cast_input_kernel<true>, dim3(grid), dim3(256), 0, st, in, (bf16_t*)out, n_pixels, c_in, c_out);
     else TFIMM_LAUNCH(cast_input_kernel<false>, dim3(grid), dim3(256), 0, st, in, (bf16_t*)out, n_pixels, c_in, c_out);
@@ -1180,8 +1243,14 @@ extern "C" int tfimm_hip_cast_input_pad(const void* in, int in_dtype, void* out,
   hipStream_t st = (hipStream_t)stream;
   const int HP = H + pad_t + pad_b, WP = W + pad_l + pad_r;
   const unsigned grid = grid_for((int64_t)B * HP * WP, 256);
-  if (in_dtype) TFIMM_LAUNCH(cast_pad4_kernel<true>, dim3(grid), dim3(256), 0, st, in, (uint2*)out, B, H, W, c_in, pad_t, pad_l, HP, WP);
-  else TFIMM_LAUNCH(cast_pad4_kernel<false>, dim3(grid), dim3(256), 0, st, in, (uint2*)out, B, H, W, c_in, pad_t, pad_l, HP, WP);
+  if (in_dtype && c_in == 3 && (W & 3) == 0 && (((uintptr_t)in & 7) == 0)) {
+    const int64_t work = (int64_t)B * H * (W / 4) + (int64_t)B * ((int64_t)HP * WP - (int64_t)H * W);
+    TFIMM_LAUNCH(cast_pad4_quad_kernel, dim3(grid_for(work, 256)), dim3(256), 0, st, (const uint2*)in, (uint2*)out, B, H, W, pad_t, pad_l, HP, WP);
+  } else if (in_dtype) {
+    TFIMM_LAUNCH(cast_pad4_kernel<true>, dim3(grid), dim3(256), 0, st, in, (uint2*)out, B, H, W, c_in, pad_t, pad_l, HP, WP);
+  } else {
+    TFIMM_LAUNCH(cast_pad4_kernel<false>, dim3(grid), dim3(256), 0, st, in, (uint2*)out, B, H, W, c_in, pad_t, pad_l, HP, WP);
+  }
   return 0;
 }
 

@@ -640,6 +640,26 @@ def _():
     return max(_err(_cpu(got), ref), _err(_cpu(gotb), ref), ok5), 1e-6
 
 
+@case("cast_input_bf16_rgb_four_pixels_per_thread")
+def _():
+    """bf16 RGB images whose width is a multiple of four take the 8-byte-load kernels: flat (3 -> 4 channels) and zero-bordered
+    with asymmetric pads; bit exact, every border pixel zero, nothing written twice with a different value"""
+    import hip_ops as H
+    r = _rng(84)
+    worst = 0.0
+    for (B, Hh, Ww, pad) in ((2, 5, 8, (3, 2, 3, 3)), (3, 7, 12, (0, 1, 2, 0)), (1, 1, 4, (1, 1, 1, 1)), (2, 6, 20, (3, 3, 3, 2))):
+        x = _bf(r.standard_normal((B, Hh, Ww, 3)))
+        ref4 = np.concatenate([x, np.zeros((B, Hh, Ww, 1), np.float32)], -1)
+        flat = H.cast_input(H.dev_bf16(x), 4)
+        padded = H.cast_input_pad(H.dev_bf16(x), pad)
+        H.sync()
+        pt, pb, pl, pr = pad
+        refp = np.zeros((B, Hh + pt + pb, Ww + pl + pr, 4), np.float32)
+        refp[:, pt:pt + Hh, pl:pl + Ww] = ref4
+        worst = max(worst, float(np.abs(_cpu(flat) - ref4).max()), float(np.abs(_cpu(padded) - refp).max()))
+    return worst, 0.0
+
+
 def _preprocess_ref(u8, mean, std):
     """create_preprocessing in float32 on the host (models/factory.py:165-167), then the bf16 rounding of cast_input."""
     x = u8.astype(np.float32) / np.float32(255.0)
