@@ -56,7 +56,8 @@ def _run_blob(blob, x, in_dtype=0):
 
 @pytest.mark.parametrize("name,batch", [("resnet50", 4), ("vit_tiny_patch16_224", 3), ("efficientnet_b0", 2),
                                         ("swin_tiny_patch4_window7_224", 2), ("cait_test_model", 2), ("convnext_test_model", 3),
-                                        ("seresnet_test_model", 2), ("resnet_gn_test_model", 2)])
+                                        ("seresnet_test_model", 2), ("resnet_gn_test_model", 2),
+                                        ("swin_base_patch4_window7_224", 1)])      # the fused MLP launch (tfimm_mlp_desc)
 def test_exported_plan_reproduces_the_python_engine_bit_for_bit(name, batch):
     model, x, want, blob = _export(name, batch)
     got, info = _run_blob(blob, x)

@@ -22,7 +22,7 @@ O, steps, warm = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 FAMILIES = {"resnet50": ("gemm",), "vit_base_patch16_224": ("gemm",), "swin_base_patch4_window7_224": ("gemm", "attention"),
             "efficientnet_b4": ("gemm", "dwconv")}
 def family(k):
-    if "tfimm_gemm" in k or "stem_pool" in k: return "gemm"
+    if "tfimm_gemm" in k or "stem_pool" in k or "mlp_fused" in k: return "gemm"
     if "attn_" in k or "tha_" in k: return "attention"
     if "dwconv" in k or "expand_dw" in k: return "dwconv"
     if "cast_" in k or "preprocess" in k: return "cast_input"
