@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("TFIMM_BENCH_WORKLOAD", "resnet50"), choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch of the main workload")
+    ap.add_argument("--branches", default=os.environ.get("TFIMM_BENCH_BRANCHES", "auto"),
+                    help="'auto' (default): the batch is also recorded as two half-batch slices on parallel branches of one HIP "
+                         "graph, both recordings are timed and the faster one runs in the timed region; 1 / 2: fixed")
     ap.add_argument("--micro-batch", type=int, default=int(os.environ.get("TFIMM_MICRO_BATCH", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
@@ -135,7 +138,7 @@ def synthetic_batch(cfg, batch, seed):
     return ((x - mean) / std).to(torch.bfloat16).contiguous()
 
 
-def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist, graph=True):
+def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist, graph=True, branches="auto"):
     """Timed region: barrier + sync, K steps, sync + barrier.  Returns seconds, per-kind kernel time, handles."""
     import torch
     cfg = model.cfg
@@ -161,8 +164,37 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
             print(f"warning: hipGraph recording failed ({e}); launching eagerly", file=sys.stderr)
             torch.cuda.synchronize()
 
+    # The batch as two slices on PARALLEL branches of one HIP graph (engine/graph.py CapturedBranches: same kernels, bit-equal
+    # results, launches of the two slices side by side).  "auto": both recordings are timed before the warm-up and the faster
+    # one runs in the timed region; the choice and the other mode's time are reported (config.launch, single_branch_ms_per_step).
+    forked, single_ms, forked_ms = None, None, None
+    n_br = 2 if branches == "auto" else int(branches)
+    if captured is not None and n_br > 1 and batch >= 2 * n_br:
+        from tfimm.engine.graph import CapturedBranches
+        try:
+            forked = CapturedBranches(prog.make_branches(batch, n_br), x)
+        except RuntimeError as e:
+            print(f"warning: branch recording failed ({e}); one branch", file=sys.stderr)
+            torch.cuda.synchronize()
+        if forked is not None:
+            def _time(g, n=5):
+                for _ in range(2):
+                    g.replay()
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(n):
+                    g.replay()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t) / n * 1e3
+            single_ms, forked_ms = _time(captured), _time(forked)
+            if branches == "auto" and forked_ms >= single_ms:
+                forked = None
+
     def step(events=None):
-        if captured is not None and events is None:
+        if forked is not None and events is None:
+            forked.replay()                                # one hipGraphLaunch: both branches
+            logits.copy_(forked.output(out_t).view(batch, out_t.C))
+        elif captured is not None and events is None:
             captured.replay()                              # one hipGraphLaunch: the whole layer program
             logits.copy_(plans[batch].tensor_view(out_t).view(batch, out_t.C))
         else:
@@ -216,7 +248,8 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
             s_["n"] += 1
             s_["flops"] += flops
     return dict(seconds=dt, ms_per_step=dt / steps * 1e3, kernels=stats, logits=logits, x=x, prog=prog,
-                graph=captured is not None, gathered=gathered,
+                graph=captured is not None, gathered=gathered, branches=(len(forked.plans) if forked is not None else 1),
+                single_branch_ms=single_ms, forked_ms=forked_ms,
                 eager_ms_per_step=None if eager_dt is None else eager_dt / steps * 1e3)
 
 
@@ -310,6 +343,9 @@ def roofline_of(name, wl, r, steps, batch):
                 launches_per_step=launches_per_step, avg_launch_ms=round(fam_ms / fam_n, 5),
                 family_ms_per_step=round(fam_ms / steps, 4),
                 share_of_eager_step=None if not eager else round(fam_ms / steps / eager, 3),
+                launches_measured=("one branch, full batch, launched one by one with a HIP event pair on the launch stream: the "
+                                   "kernels by themselves" + ("; the timed region ran the batch as parallel branches, where "
+                                   "launches overlap and a per-launch duration is not defined" if r.get("branches", 1) > 1 else "")),
                 per_kind={k: dict(ms_per_step=round(v["ms"] / steps, 4), launches_per_step=v["n"] / steps,
                                   tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)) for k, v in ks.items()},
                 timing="HIP event pair around every launch of the family, on the launch stream, over K eagerly launched "
@@ -497,7 +533,8 @@ def run_workload(name, args, world, rank, dist, steps, warmup, batch=0, micro_ba
     batch = batch or wl["batch"]
     model = build_model(wl["model"])
     torch.cuda.empty_cache()
-    r = measure(model, batch, micro_batch, steps, warmup, world, not args.no_kernel_events, dist, graph=not args.no_graph)
+    r = measure(model, batch, micro_batch, steps, warmup, world, not args.no_kernel_events, dist, graph=not args.no_graph,
+                branches=args.branches)
     ms = r["ms_per_step"]
     per_rank = [ms]
     if dist is not None:
@@ -514,7 +551,12 @@ def run_workload(name, args, world, rank, dist, steps, warmup, batch=0, micro_ba
         total = batch * world
         out = dict(value=round(total / ms * 1e3, 1), unit="images/sec", ms_per_step=round(ms, 4), per_gpu_batch=batch,
                    global_batch=total, per_rank_ms=per_rank, model=wl["model"], input_size=int(model.cfg.input_size[0]),
-                   launch="hipGraph replay" if r["graph"] else "eager", gflops_per_image=round(flops_img / 1e9, 3),
+                   launch=("eager" if not r["graph"] else "hipGraph replay" if r["branches"] == 1 else
+                           f"hipGraph replay, {r['branches']} parallel branches of {batch // r['branches']} images"),
+                   branches=r["branches"],
+                   single_branch_ms_per_step=None if r["single_branch_ms"] is None else round(r["single_branch_ms"], 4),
+                   forked_ms_per_step=None if r["forked_ms"] is None else round(r["forked_ms"], 4),
+                   gflops_per_image=round(flops_img / 1e9, 3),
                    model_tflops=round(flops_img * total / ms / 1e9, 1),
                    mfma_frac_whole_step=round(flops_img * batch / ms / 1e9 / 2500.0, 4),
                    roofline=roofline_of(name, wl, r, steps, batch))
@@ -590,7 +632,8 @@ def main():
                        "ranks": world, "launcher": ("bench.py spawn" if os.environ.get("TFIMM_BENCH_SPAWNED") else
                                                     "external" if launched else "in-process"),
                        "weights": "random-init (synthetic generator, seed 2021)", "launch": m["launch"],
-                       "gflops_per_image": m["gflops_per_image"]},
+                       "branches": m["branches"], "single_branch_ms_per_step": m["single_branch_ms_per_step"],
+                       "forked_ms_per_step": m["forked_ms_per_step"], "gflops_per_image": m["gflops_per_image"]},
             "per_rank_ms": m["per_rank_ms"], "model_tflops": m["model_tflops"],
             "roofline": m["roofline"], "cpu_baseline": m.get("cpu_baseline"), "parity_vs_oracle": m.get("parity_vs_oracle"),
             "headline": {k: (v["value"] if v and "value" in v else None)

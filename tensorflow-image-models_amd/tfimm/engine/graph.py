@@ -202,6 +202,17 @@ class Program:
     def make_plan(self, batch: int, device: str = "cuda") -> "Plan":
         return Plan(self, batch, device)
 
+    def make_branches(self, batch: int, parts: int = 2, device: str = "cuda") -> List["Plan"]:
+        """``parts`` plans over consecutive slices of one batch (sizes as even as possible, each with its own activation
+        slabs, all on this program's weights): the branches of ``CapturedBranches``."""
+        return [Plan(self, nb, device) for nb in branch_sizes(batch, parts)]
+
+
+def branch_sizes(batch: int, parts: int) -> List[int]:
+    """Images per branch: ``parts`` consecutive slices of the batch, as even as possible, none empty."""
+    parts = max(1, min(int(parts), int(batch)))
+    return [batch // parts + (1 if i < batch % parts else 0) for i in range(parts)]
+
 
 # ---------------------------------------------------------------------------------------
 # Builder: one method per fused kernel
@@ -1607,6 +1618,48 @@ class CapturedPlan:
 
     def replay(self):
         self.graph.replay()
+
+
+class CapturedBranches:
+    """Several plans, each over its own slice of ONE batch, recorded into one HIP graph as PARALLEL branches: the recording
+    stream forks into a side stream per further plan and joins them at the end, so a replay is still one hipGraphLaunch.
+    Kernels of different branches run side by side wherever a launch leaves compute units idle (196 tiles on 256 CUs, the
+    tail of every launch) and an HBM-bound launch of one branch overlaps an MFMA-bound one of the other; every image is
+    still computed by the same kernels on the same operands (results are bit-equal to the single plan's: the engine's
+    kernels never mix images).  Measured at the scored batch sizes (tools/two_stream_probe.py): ResNet-50 +6 %, Swin-B +12 %,
+    EfficientNet-B4 +-0, ViT-B/16 -4 % -- callers pick per workload (bench.py --branches auto times both)."""
+
+    def __init__(self, plans: List["Plan"], x_dev, norm=None):
+        import torch
+        self.plans = plans
+        self.static_input = x_dev
+        bounds = np.cumsum([0] + [p.batch for p in plans])
+        assert bounds[-1] == x_dev.shape[0], (bounds, tuple(x_dev.shape))
+        self.slices = [(int(bounds[i]), int(bounds[i + 1])) for i in range(len(plans))]
+        for p, (lo, hi) in zip(plans, self.slices):      # lazy host-side initialisation happens outside the recording
+            p.run(x_dev[lo:hi], norm=norm)
+        torch.cuda.synchronize()
+        self.side = [torch.cuda.Stream() for _ in plans[1:]]
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            main = torch.cuda.current_stream()
+            for s in self.side:
+                s.wait_stream(main)                          # fork
+            lo, hi = self.slices[0]
+            plans[0].run(x_dev[lo:hi], norm=norm)
+            for s, p, (lo, hi) in zip(self.side, plans[1:], self.slices[1:]):
+                with torch.cuda.stream(s):
+                    p.run(x_dev[lo:hi], norm=norm)
+            for s in self.side:
+                main.wait_stream(s)                          # join
+
+    def replay(self):
+        self.graph.replay()
+
+    def output(self, t: "TRef"):
+        """The program output ``t`` of the whole batch (the branches' slices concatenated)."""
+        import torch
+        return torch.cat([p.tensor_view(t) for p in self.plans], dim=0)
 
 
 def _hip_memset_async(ptr: int, nbytes: int, stream_ptr: int) -> int:

@@ -1,0 +1,48 @@
+"""A batch as slices on parallel branches of one HIP graph (engine/graph.py CapturedBranches, Model.branches): the same
+kernels on the same operands, so the result must equal the single-plan forward BIT FOR BIT -- eagerly (first call) and
+from the recorded graph (later calls), for even and uneven slices."""
+import numpy as np
+import pytest
+
+import test_architectures  # noqa: F401
+import tfimm
+from tfimm.engine.graph import branch_sizes
+from tfimm.utils.init import synthetic_weights
+
+
+def test_branch_sizes():
+    assert branch_sizes(256, 2) == [128, 128]
+    assert branch_sizes(7, 2) == [4, 3] and branch_sizes(7, 3) == [3, 2, 2]
+    assert branch_sizes(2, 5) == [1, 1] and branch_sizes(5, 1) == [5] and branch_sizes(5, 0) == [5]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,batch,parts", [("resnet50", 8, 2), ("swin_tiny_patch4_window7_224", 7, 2),
+                                              ("efficientnet_b0", 9, 3), ("convnext_test_model", 6, 2)])
+def test_parallel_branches_reproduce_the_single_plan_bit_for_bit(name, batch, parts):
+    import model_checks as mc
+    model = tfimm.create_model(name)
+    model.set_weights(synthetic_weights(model, 2021))
+    x = mc.make_input(model.cfg, batch)
+    want = model(x).numpy()
+    model.branches = parts
+    first = model(x).numpy()            # slices launched one after the other
+    second = model(x).numpy()           # one hipGraphLaunch, parallel branches
+    third = model(x).numpy()
+    assert np.array_equal(first, want) and np.array_equal(second, want) and np.array_equal(third, want)
+    y, feats = model(x, return_features=True)
+    model.branches = 1
+    y1, feats1 = model(x, return_features=True)
+    assert np.array_equal(y.numpy(), y1.numpy())
+    assert all(np.array_equal(feats[k].numpy(), feats1[k].numpy()) for k in feats1)
+
+
+@pytest.mark.gpu
+def test_small_batches_keep_one_branch():
+    import model_checks as mc
+    model = tfimm.create_model("resnet_test_model_1")
+    model.set_weights(synthetic_weights(model, 2021))
+    model.branches = 2
+    x = mc.make_input(model.cfg, 3)
+    model(x)
+    assert not [k for k in model._plans if "branches" in k]       # fewer than 2 images per branch: the plain path
