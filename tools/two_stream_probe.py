@@ -52,7 +52,28 @@ def main():
         for s in streams:
             cur.wait_stream(s)
 
+    def free_running(skew_ms):
+        """no join between steps: every stream replays its slice back to back, the second one started ``skew_ms`` late"""
+        cur = torch.cuda.current_stream()
+        for s in streams:
+            s.wait_stream(cur)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k, (s, h) in enumerate(zip(streams, halves)):
+            with torch.cuda.stream(s):
+                if k and skew_ms > 0:
+                    torch.cuda._sleep(int(skew_ms * 1e-3 * 2.0e9 * k))
+        for _ in range(iters):
+            for s, h in zip(streams, halves):
+                with torch.cuda.stream(s):
+                    h.replay()
+        torch.cuda.synchronize()
+        return ((time.perf_counter() - t0) * 1e3 - skew_ms * (parts - 1)) / iters
+
     t_full, t_seq, t_par = timed(full.replay), timed(seq), timed(par)
+    for skew in (0.0, 0.25, 0.5):
+        free_running(skew * t_full)
+        print(f"   free-running streams, second one {skew:.2f} of a forward late: {free_running(skew * t_full):.3f} ms per step")
     print(f"{name} B={B}: full-batch graph {t_full:.3f} ms; {parts} x B={hb} one stream {t_seq:.3f} ms; {parts} streams {t_par:.3f} ms "
           f"({B / t_par:.1f} k img/s vs {B / t_full:.1f})")
 
