@@ -313,6 +313,14 @@ __global__ void __launch_bounds__(256, 2) gemm_duo_kernel(const GemmStreamArgs p
       cur = cur + 1 == NS ? 0 : cur + 1;
     }
 
+    // ---- the tile's tables (bias, LayerNorm statistics / correction fragments) were requested in its FIRST k-step; a tile
+    //      of three or more k-tiles has waited for them in its third step (the counted wait there leaves only the second
+    //      step's pieces in flight).  With exactly two k-tiles no wait has covered them yet: without this one the epilogue
+    //      read the PREVIOUS tile's bias whenever the 1-KiB table piece was slower than two k-steps (found by the
+    //      eager-vs-replay bit-equality test on EfficientNet-B4's K = 56 expansions: one 256 x 128 tile in ~7000 wrong,
+    //      in some runs).  Younger than the tables: the two k-steps' pieces -- the second step's (and this tile's first
+    //      residual rows, requested in front of them) may stay in flight.
+    if (nk == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE + (FAST ? 0 : ITS)) : "memory");
     // ---- epilogue through the stage of the k-tile consumed last (cur - 1): every wave must be done reading it; its
     //      refill is issued behind the next step's barrier, i.e. after every wave finished this epilogue
     __builtin_amdgcn_s_barrier();

@@ -27,3 +27,32 @@ def test_conv_chain_splits_oversize_batches_into_image_chunks():
     env = dict(os.environ, TFIMM_CHAIN_LIMIT=str(5 * 1000 * 1000))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("K,N,act,residual", [(56, 336, "swish", False), (64, 384, "", True), (40, 128, "relu", False)])
+def test_two_ktile_tiles_of_the_duo_kernel_are_reproducible(K, N, act, residual):
+    """Tile hint 30 with exactly TWO 32-wide k-tiles (EfficientNet-B4's K = 56 expansions): the tile's bias table is requested
+    in the first k-step and nothing waited for it before the epilogue -- once in a few thousand tiles, in some runs, a tile
+    got the previous tile's bias (a different column block: errors of several units).  Many tiles, many launches, the L2 /
+    Infinity Cache flushed in between; every result bit-equal to the 256x128 stream tile's (hint 22: the same MFMA order)."""
+    import numpy as np
+    import torch
+
+    import hip_ops as H
+    from tfimm.engine import pack
+    M = 589824 // 2
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    r = np.random.default_rng(4)
+    wt, _ = pack.pack_dense((r.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32), None)
+    wd, b = H.dev_bits(wt), H.dev_f32(r.standard_normal(N).astype(np.float32))
+    res = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16) if residual else None
+    flush = torch.empty(1 << 29, dtype=torch.uint8, device="cuda")
+    ref = H.gemm(a, wd, N, K, bias=b, residual=res, act=act, tile_hint=22).view(torch.int16).clone()
+    for run in range(16):
+        if run % 2:
+            flush.fill_(run)
+        out = H.gemm(a, wd, N, K, bias=b, residual=res, act=act, tile_hint=30)
+        H.sync()
+        bad = int((out.view(torch.int16) != ref).sum().item())
+        assert bad == 0, f"launch {run}: {bad} elements differ from the stream tile's result"
