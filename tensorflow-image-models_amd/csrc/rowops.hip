@@ -1518,8 +1518,24 @@ extern "C" int tfimm_hip_patch_merge_ln(const void* x, void* y, const float* gam
   return 0;
 }
 
+__global__ void fill_bytes_kernel(uint32_t* dst, uint32_t word, size_t n_words) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) dst[i] = word;
+}
+
 extern "C" int tfimm_hip_memset_async(void* dst, int value, size_t bytes, void* stream) {
   if (!dst) TFIMM_FAIL(TFIMM_EINVAL, "memset_async: null pointer");
+  // A fill KERNEL, not hipMemsetAsync: recorded into a HIP graph the latter becomes a memset node, and with those the
+  // squeeze sums of a replayed EfficientNet plan came back as garbage from the fourth replay on in one buffer layout
+  // (tools/flaky_hunt.py, every tensor in its own allocation; bit-exact with this kernel in the same layout, and with
+  // memset nodes in the usual layout -- ROCm 7.2; TFIMM_MEMSET_NODE=1 restores the runtime call for comparison).
+  static const bool use_node = getenv("TFIMM_MEMSET_NODE") && atoi(getenv("TFIMM_MEMSET_NODE")) != 0;
+  if (!use_node && (bytes & 3) == 0 && (((uintptr_t)dst) & 3) == 0) {
+    const uint32_t b = (uint32_t)(value & 0xff), word = b | (b << 8) | (b << 16) | (b << 24);
+    const size_t n = bytes / 4;
+    if (n == 0) return 0;
+    TFIMM_LAUNCH(fill_bytes_kernel, dim3(grid_for((int64_t)n, 256)), dim3(256), 0, (hipStream_t)stream, (uint32_t*)dst, word, n);
+    return 0;
+  }
   TFIMM_HIP_CHECK(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
   return 0;
 }

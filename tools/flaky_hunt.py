@@ -46,6 +46,24 @@ def main():
     torch.cuda.synchronize()
     ref = sums()
     bad = {}
+    small = {}       # copies of the small tensors of the first run (inputs / extra outputs of a differing op are compared by value)
+    for t in prog.tensors:
+        if t.dtype != "raw" and t.rows * t.C * B <= (1 << 24):
+            small[t.id] = plan.tensor_view(t).clone()
+
+    def explain(op):
+        for tid in list(op.inputs) + [op.output] + list(op.extra_outputs):
+            t = prog.tensors[tid]
+            if tid in small:
+                cur, old = plan.tensor_view(t), small[tid]
+                n = int((cur.view(torch.int32) != old.view(torch.int32)).sum().item()) if cur.dtype == torch.float32 else \
+                    int((cur.view(torch.int16) != old.view(torch.int16)).sum().item())
+                extra = ""
+                if n and cur.dtype == torch.float32 and "sums" in (t.name or ""):
+                    d = (cur.reshape(B, -1).view(torch.int64) - old.reshape(B, -1).view(torch.int64))
+                    nz = torch.nonzero(d)
+                    extra = f" int64 diffs: {d[d != 0][:6].tolist()} at (image, channel) {nz[:6].tolist()}"
+                print(f"      tensor {tid} '{t.name}' rows={t.rows} C={t.C} {t.dtype}: {n} words differ from run 0{extra}")
     def check(tag):
         torch.cuda.synchronize()
         cur = sums()
@@ -56,6 +74,10 @@ def main():
             op = ops[i]
             print(f"{tag}: {len(diff)} outputs differ, first = op {i} {op.kind} {op.cite} "
                   f"{ {k: v for k, v in op.attrs.items() if k in ('M', 'N', 'K', 'C', 'k', 'stride', 'H', 'W', 'OH', 'Cin', 'act', 'mode')} }", flush=True)
+            if len(bad[i]) <= 2:
+                explain(op)
+                if i > 0:
+                    explain(ops[i - 1])
     for e in range(n_eager):
         plan.run(x)
         check(f"eager {e}")
