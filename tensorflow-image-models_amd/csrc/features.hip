@@ -193,7 +193,8 @@ extern "C" int tfimm_hip_group_norm(const void* x, const float* gamma, const flo
   if (B > 65535) TFIMM_FAIL(TFIMM_EUNSUP, "group_norm: batch %d > 65535", B);
   if ((size_t)C * 16 > 64 * 1024) TFIMM_FAIL(TFIMM_EUNSUP, "group_norm: %d channels", C);
   hipStream_t st = (hipStream_t)stream;
-  TFIMM_HIP_CHECK(hipMemsetAsync(stats_ws, 0, (size_t)B * groups * 2 * sizeof(tfimm_sq_t), st));
+  // (the library's fill kernel, not a runtime memset: see tfimm_hip_memset_async)
+  if (int rc = tfimm_hip_memset_async(stats_ws, 0, (size_t)B * groups * 2 * sizeof(tfimm_sq_t), stream)) return rc;
   // Rows per workgroup: a function of the image size ONLY.  A thread sums its rows of a run in fp32 before it converts to fixed
   // point, so a run length chosen from the batch size (as it was: rows * B / 2048) made the statistics -- and the logits, by
   // up to 8e-3 at batch 32 against batch 2 -- depend on the batch.  8..64 rows: >= 2048 workgroups from batch 42 on at 56 x 56.
