@@ -31,6 +31,7 @@ done
 bash tools/gpu_traffic.sh > $O/traffic.log 2>&1; tail -14 $O/traffic.log; cp gpurun_out/traffic.json $O/traffic.json
 rm -rf gpurun_out/traffic_*
 # reproducibility: every op output of the four workloads bit-equal over eager launches and graph replays
-for m in "resnet50 256" "vit_base_patch16_224 512" "swin_base_patch4_window7_224 256" "efficientnet_b4 256"; do
+for m in "resnet50 256" "vit_base_patch16_224 512" "swin_base_patch4_window7_224 256" "efficientnet_b4 256" "convnext_base 128" \
+         "seresnet50 64" "resnet50_gn 32" "cait_xxs24_224 64" "efficientnet_b0 64" "mobilenet_v2_100 64"; do
   timeout 400 python tools/flaky_hunt.py $m 12 3 2>/dev/null | tail -1
 done > $O/reproducibility.txt; cat $O/reproducibility.txt
