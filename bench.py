@@ -169,7 +169,7 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
     # one runs in the timed region; the choice and the other mode's time are reported (config.launch, single_branch_ms_per_step).
     forked, single_ms, forked_ms = None, None, None
     n_br = 2 if branches == "auto" else int(branches)
-    if captured is not None and n_br > 1 and batch >= 2 * n_br:
+    if captured is not None and n_br > 1 and batch >= 2 * n_br and prog.supports_branches():
         from tfimm.engine.graph import CapturedBranches
         try:
             forked = CapturedBranches(prog.make_branches(batch, n_br), x)

@@ -57,6 +57,7 @@ struct ThaArgs {
   int kstr;       // LDS row stride (elements) of the K / Q blocks (heads padded to whole 32-wide k-steps)
   int vstr;       // LDS row stride of the V block
   int q_in_lds;
+  const float* wdev;   // DEVICE copy of the mixing layers [wl H*H | bl H | ww H*H | bw H] (tfimm_tha_desc.proj_dev), or null
 };
 
 constexpr int THA_KB = 32;        // keys staged per step
@@ -87,13 +88,23 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p, const ThaWeig
   const bool q_ok = q < p.n;
   const int CH = D / 8;             // 16-byte chunks per token row of one of q / k / v
 
-  for (int id = tid; id < H * H; id += 256) {
-    Wm[id] = w.wl[id];
-    Wm[H * H + H + id] = w.ww[id];
-  }
-  if (tid < H) {
-    Wm[H * H + tid] = w.bl[tid] * LOG2E;
-    Wm[2 * H * H + H + tid] = w.bw[tid];
+  if (p.wdev) {
+    // from device memory, in Wm's own order.  (From the argument segment -- the `else` below -- the result of this kernel
+    // stopped being reproducible as soon as launches of a second stream ran next to it: tools/branch_hunt.py, CaiT under
+    // parallel branches; a 2 KiB by-value struct read with vector loads.  Plans always pass the device copy.)
+    for (int id = tid; id < 2 * (H * H + H); id += 256) {
+      const float v = p.wdev[id];
+      Wm[id] = (id >= H * H && id < H * H + H) ? v * LOG2E : v;
+    }
+  } else {
+    for (int id = tid; id < H * H; id += 256) {
+      Wm[id] = w.wl[id];
+      Wm[H * H + H + id] = w.ww[id];
+    }
+    if (tid < H) {
+      Wm[H * H + tid] = w.bl[tid] * LOG2E;
+      Wm[2 * H * H + H + tid] = w.bw[tid];
+    }
   }
   // staging map (no divisions): 8 threads per row, thread (row = tid >> 3) walks chunks (tid & 7) + 8 j;
   // chunk c of a token row belongs to head c / CPH and lands at column head * HP + (c % CPH) * 8
@@ -465,6 +476,7 @@ extern "C" int tfimm_hip_talking_heads_attention(const tfimm_tha_desc* dp, void*
   a.dmodel = d.heads * d.hd; a.ld = 3 * a.dmodel;
   a.qchunks = (d.n_tokens + 63) / 64;
   a.kstr = 0; a.vstr = 0; a.q_in_lds = 0;
+  a.wdev = d.proj_dev;
   if (d.heads > 16) TFIMM_FAIL(TFIMM_EUNSUP, "talking_heads_attention: %d heads > 16", d.heads);
   ThaWeights w;
   for (int i = 0; i < d.heads * d.heads; ++i) { w.wl[i] = d.proj_l_w[i]; w.ww[i] = d.proj_w_w[i]; }

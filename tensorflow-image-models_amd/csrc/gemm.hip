@@ -264,22 +264,29 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
                       (d.res_mod == 0 || d.res_mod >= 128) && (d.remap_in == 0 || d.remap_in >= 128)) ? 1 : 0;
       // epilogue flavour: 0 catch-all, 1 vector, 2 vector without residual (arithmetic in the accumulator layout)
       const int ei = vi ? (d.residual ? 1 : 2) : 0;
+      // Workgroups per CU of every tile: the minimum over the epilogue flavours of an operand kind, queried for ALL
+      // flavours on the first call.  (It used to be filled in flavour by flavour as launches came: the minimum -- and with
+      // it the tile the heuristic picks for a shape without a table entry, and the grid -- depended on which OTHER layers
+      // had been launched before, so the first forward of a model could differ in the last bits from its later ones:
+      // tests/test_gpu_scored_batches.py under TFIMM_BRANCHES=2, cait_xxs24_224.)
       static int occ[TFIMM_GEMM_STREAM_NUM_TILES][2] = {};
-      static bool ready[2][3] = {};
-      if (!ready[fi][ei]) {
-        for (int i = 0; i < TFIMM_GEMM_STREAM_NUM_TILES; ++i) {
-          const StreamTileCfg* t = stream_tile_table(i);
-          if (!t->fn[fi][ei]) {           // the duo tile has no catch-all flavour (redirected below): two workgroups per CU
-            if (occ[i][fi] == 0) occ[i][fi] = 2;
-            continue;
-          }
-          TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)t->fn[fi][ei], hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_bytes));
-          int nb = 0;
-          TFIMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)t->fn[fi][ei], t->threads, (size_t)t->lds_bytes));
-          nb = nb < 1 ? 1 : (nb > 4 ? 4 : nb);
-          if (occ[i][fi] == 0 || nb < occ[i][fi]) occ[i][fi] = nb;
-        }
-        ready[fi][ei] = true;
+      static bool ready = false;
+      if (!ready) {
+        for (int f = 0; f < 2; ++f)
+          for (int e = 0; e < 3; ++e)
+            for (int i = 0; i < TFIMM_GEMM_STREAM_NUM_TILES; ++i) {
+              const StreamTileCfg* t = stream_tile_table(i);
+              if (!t->fn[f][e]) {         // the duo tile has no catch-all flavour (redirected below): two workgroups per CU
+                if (occ[i][f] == 0) occ[i][f] = 2;
+                continue;
+              }
+              TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)t->fn[f][e], hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_bytes));
+              int nb = 0;
+              TFIMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)t->fn[f][e], t->threads, (size_t)t->lds_bytes));
+              nb = nb < 1 ? 1 : (nb > 4 ? 4 : nb);
+              if (occ[i][f] == 0 || nb < occ[i][f]) occ[i][f] = nb;
+            }
+        ready = true;
       }
       int occ_f[TFIMM_GEMM_STREAM_NUM_TILES];
       for (int i = 0; i < TFIMM_GEMM_STREAM_NUM_TILES; ++i) occ_f[i] = occ[i][fi];

@@ -56,7 +56,7 @@ class ThaDesc(C.Structure):
         ("qkv", C.c_void_p), ("out", C.c_void_p),
         ("proj_l_w", C.c_void_p), ("proj_l_b", C.c_void_p), ("proj_w_w", C.c_void_p), ("proj_w_b", C.c_void_p),
         ("batch", C.c_int32), ("n_tokens", C.c_int32), ("heads", C.c_int32), ("hd", C.c_int32),
-        ("scale", C.c_float),
+        ("scale", C.c_float), ("proj_dev", C.c_void_p),
     ]
 
 

@@ -202,6 +202,13 @@ class Program:
     def make_plan(self, batch: int, device: str = "cuda") -> "Plan":
         return Plan(self, batch, device)
 
+    def supports_branches(self) -> bool:
+        """False for programs with the talking-heads attention launch (CaiT).  tools/branch_hunt.py: next to launches of a
+        second stream the H = 4 instance of that kernel (cait_xxs24 / xxs36) is not bit-reproducible -- alone it is, with any
+        number of workgroups per CU (tools/tha_repro_probe.py), and so is every other configuration tried under parallel
+        branches (profiles/NOTES_r03.md section 9: open).  Until that is understood such programs keep one branch."""
+        return not any(op.kind == "talking_heads_attention" for op in self.ops)
+
     def make_branches(self, batch: int, parts: int = 2, device: str = "cuda") -> List["Plan"]:
         """``parts`` plans over consecutive slices of one batch (sizes as even as possible, each with its own activation
         slabs, all on this program's weights): the branches of ``CapturedBranches``."""
@@ -688,6 +695,10 @@ class Builder:
         for role, nm in (("wl", "proj_l/kernel"), ("bl", "proj_l/bias"), ("ww", "proj_w/kernel"), ("bw", "proj_w/bias")):
             consts[role] = p.new_const(np.ascontiguousarray(self.wget(f"{prefix}/{nm}"), dtype=np.float32), f"{prefix}/{nm}",
                                        keep_host=True)
+        # the same four arrays once more as ONE device constant [wl | bl | ww | bw]: what the MFMA kernel reads (tfimm_tha_desc.proj_dev)
+        packed = np.concatenate([np.asarray(self.wget(f"{prefix}/{nm}"), dtype=np.float32).reshape(-1)
+                                 for nm in ("proj_l/kernel", "proj_l/bias", "proj_w/kernel", "proj_w/bias")])
+        consts["dev"] = p.new_const(np.ascontiguousarray(packed), f"{prefix}/proj_l+proj_w:packed")
         n = qkv.rows
         p.add("talking_heads_attention", [qkv], out, consts, cite=cite, heads=heads, hd=hd, scale=float(scale),
               n_tokens=n, flops=4 * heads * n * n * hd + 4 * heads * heads * n * n)
@@ -1139,6 +1150,7 @@ class Plan:
                 self._keepalive.append(host)
                 d.proj_l_w, d.proj_l_b = host["wl"].ctypes.data, host["bl"].ctypes.data
                 d.proj_w_w, d.proj_w_b = host["ww"].ctypes.data, host["bw"].ctypes.data
+                d.proj_dev = self.cptr(op.consts["dev"])
                 d.batch, d.n_tokens, d.heads, d.hd, d.scale = B, a["n_tokens"], a["heads"], a["hd"], a["scale"]
                 self._keepalive.append(d)
                 self.calls.append((lib.tfimm_hip_talking_heads_attention, (C.byref(d),)))

@@ -225,7 +225,7 @@ class Model:
         prog = self.program(H, W, want_features)
         mb = self.micro_batch or B
         mb = min(mb, B)
-        if self.branches > 1 and mb == B and B >= 2 * self.branches:
+        if self.branches > 1 and mb == B and B >= 2 * self.branches and prog.supports_branches():
             return self._run_branches(prog, xd, norm, want_features)
         results: Dict[str, list] = {k: [] for k in prog.outputs}
         for start in range(0, B, mb):

@@ -421,7 +421,7 @@ def _tha_ref(qkv, B, N, heads, hd, scale, wl, bl, ww, bw):
     return o.transpose(0, 2, 1, 3).reshape(B * N, heads * hd)
 
 
-def _tha_case(B, N, heads, hd, seed):
+def _tha_case(B, N, heads, hd, seed, use_dev=True):
     import hip_ops as H
     r = _rng(seed)
     qkv = _bf(r.standard_normal((B * N, 3 * heads * hd)))
@@ -431,7 +431,7 @@ def _tha_case(B, N, heads, hd, seed):
     bw = (0.02 * r.standard_normal(heads)).astype(np.float32)
     scale = hd ** -0.5
     ref = _tha_ref(qkv, B, N, heads, hd, scale, wl, bl, ww, bw)
-    got = H.talking_heads_attention(H.dev_bf16(qkv), B, N, heads, hd, scale, wl, bl, ww, bw)
+    got = H.talking_heads_attention(H.dev_bf16(qkv), B, N, heads, hd, scale, wl, bl, ww, bw, use_dev=use_dev)
     H.sync()
     return _err(_cpu(got), ref), 1.5e-2   # mixed probabilities are rounded to bf16 before P.V
 
@@ -444,6 +444,8 @@ CASES["tha_33_h2_hd32"] = lambda: _tha_case(2, 33, 2, 32, 164)
 CASES["tha_17_h3_hd32"] = lambda: _tha_case(2, 17, 3, 32, 165)
 CASES["tha_577_h4_hd48_long"] = lambda: _tha_case(1, 577, 4, 48, 166)
 CASES["tha_9_h1_hd32"] = lambda: _tha_case(2, 9, 1, 32, 167)
+CASES["tha_196_h4_hd48_weights_by_value"] = lambda: _tha_case(2, 196, 4, 48, 160, use_dev=False)   # no device copy: argument segment
+CASES["tha_100_h16_hd48_weights_by_value"] = lambda: _tha_case(1, 100, 16, 48, 163, use_dev=False)
 CASES["tha_generic_16_h2_hd2"] = lambda: _tha_case(3, 16, 2, 2, 168)       # the reference's mini: catch-all kernel
 CASES["tha_generic_40_h5_hd24"] = lambda: _tha_case(2, 40, 5, 24, 169)
 

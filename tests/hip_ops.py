@@ -122,12 +122,15 @@ def attention(qkv, batch, n_tokens, heads, hd, scale, window=0, shift=0, res=(0,
     return out
 
 
-def talking_heads_attention(qkv, batch, n_tokens, heads, hd, scale, wl, bl, ww, bw):
-    """wl, bl, ww, bw: HOST numpy fp32 arrays (the C ABI takes the two head-mixing layers by host pointer)."""
+def talking_heads_attention(qkv, batch, n_tokens, heads, hd, scale, wl, bl, ww, bw, use_dev=True):
+    """wl, bl, ww, bw: HOST numpy fp32 arrays (the C ABI takes the two head-mixing layers by host pointer); ``use_dev``: also
+    hand over their packed DEVICE copy (tfimm_tha_desc.proj_dev: what plans do)."""
     out = torch.empty(batch * n_tokens, heads * hd, dtype=torch.bfloat16, device=DEV)
     d = ffi.ThaDesc()
     d.qkv, d.out = ptr(qkv), ptr(out)
     host = [np.ascontiguousarray(a, dtype=np.float32) for a in (wl, bl, ww, bw)]
+    dev = torch.from_numpy(np.concatenate([a.reshape(-1) for a in host])).to(DEV) if use_dev else None
+    d.proj_dev = ptr(dev)
     d.proj_l_w, d.proj_l_b, d.proj_w_w, d.proj_w_b = (a.ctypes.data for a in host)
     d.batch, d.n_tokens, d.heads, d.hd, d.scale = batch, n_tokens, heads, hd, float(scale)
     ffi.check(lib.tfimm_hip_talking_heads_attention(C.byref(d), stream()), "talking_heads_attention")

@@ -46,3 +46,19 @@ def test_small_batches_keep_one_branch():
     x = mc.make_input(model.cfg, 3)
     model(x)
     assert not [k for k in model._plans if "branches" in k]       # fewer than 2 images per branch: the plain path
+
+
+@pytest.mark.gpu
+def test_talking_heads_programs_keep_one_branch():
+    """CaiT: the talking-heads launch is not bit-reproducible next to launches of another stream (Program.supports_branches,
+    profiles/NOTES_r03.md section 9) -- such programs ignore ``branches`` and stay reproducible."""
+    import model_checks as mc
+    model = tfimm.create_model("cait_xxs24_224")
+    model.set_weights(synthetic_weights(model, 2021))
+    assert not model.program().supports_branches()
+    x = mc.make_input(model.cfg, 8)
+    want = model(x).numpy()
+    model.branches = 2
+    runs = [model(x).numpy() for _ in range(3)]
+    assert all(np.array_equal(r, want) for r in runs)
+    assert not [k for k in model._plans if "branches" in k]
