@@ -505,7 +505,13 @@ extern "C" int tfimm_hip_talking_heads_attention(const tfimm_tha_desc* dp, void*
                       (size_t)((2 * (d.heads * d.heads + d.heads) + 3) / 4 * 4) * 4;
   const size_t qbytes = (size_t)64 * a.kstr * 2;
   a.q_in_lds = (base + qbytes <= 160 * 1024) ? 1 : 0;   // else Q fragments are re-read from L1/L2 per key tile
-  const size_t lds = base + (a.q_in_lds ? qbytes : 0);
+  size_t lds = base + (a.q_in_lds ? qbytes : 0);
+  {
+    // experiment switch (profiles/NOTES_r03.md section 9): ask for more LDS than the kernel needs so that no other workgroup
+    // shares its CU -- TFIMM_THA_LDS_KIB=160: nothing with an LDS allocation fits next to it
+    static const int want = getenv("TFIMM_THA_LDS_KIB") ? atoi(getenv("TFIMM_THA_LDS_KIB")) : 0;
+    if (want > 0 && (size_t)want * 1024 > lds && want <= 160) lds = (size_t)want * 1024;
+  }
   if (lds > 160 * 1024) TFIMM_FAIL(TFIMM_EUNSUP, "talking_heads_attention: embed dim %d needs %zu bytes of LDS", a.dmodel, lds);
   return d.hd == 32 ? launch_tha_heads<2>(a, w, lds, st) : launch_tha_heads<3>(a, w, lds, st);
 }

@@ -112,6 +112,12 @@ int pick_dma_tile(const tfimm_gemm_desc& d) {
 // ceil(tiles / slots) rounds; score = efficiency x useful area x fill of those rounds.
 int pick_stream_tile(const tfimm_gemm_desc& d, const int* occ) {
   if (d.tile_hint > 20 && d.tile_hint <= 20 + TFIMM_GEMM_STREAM_NUM_TILES) return d.tile_hint - 21;
+  {
+    // debugging aid: TFIMM_GEMM_AUTO_TILE=k sends every launch WITHOUT a hint to stream tile k (0-based) -- used to find which
+    // tile kernel disturbs a co-resident workgroup of another kernel (profiles/NOTES_r03.md section 9)
+    static const int forced = getenv("TFIMM_GEMM_AUTO_TILE") ? atoi(getenv("TFIMM_GEMM_AUTO_TILE")) : -1;
+    if (forced >= 0 && forced < TFIMM_GEMM_STREAM_NUM_TILES && forced != 7) return forced;
+  }
   static const double eff[TFIMM_GEMM_STREAM_NUM_TILES] = {1.00, 0.90, 0.75, 0.70, 0.55, 0.90, 0.75, 0.0, 0.40, 0.0};
   const int cus = num_cu();
   int best = 2;
