@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define TFIMM_HIP_ABI_VERSION 2
+/* 3: tfimm_tha_desc grew (proj_dev), tfimm_hip_mlp_fused / tfimm_hip_plan_* / tfimm_hip_ref_* added (round 3) */
+#define TFIMM_HIP_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define TFIMM_API __attribute__((visibility("default")))

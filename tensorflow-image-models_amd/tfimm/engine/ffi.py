@@ -183,7 +183,7 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the ABI drifted
         fn.restype = res
         fn.argtypes = args
-    if lib.tfimm_hip_abi_version() != 2:
+    if lib.tfimm_hip_abi_version() != 3:
         raise ImportError("libtfimm_hip.so ABI version mismatch")
     return lib
 

@@ -25,7 +25,7 @@ def test_header_symbols_exported_and_bound():
 
 
 def test_abi_version_and_error_string():
-    assert ffi.lib.tfimm_hip_abi_version() == 2
+    assert ffi.lib.tfimm_hip_abi_version() == 3
     d = ffi.GemmDesc()
     rc = ffi.lib.tfimm_hip_gemm(ctypes.byref(d), None)
     assert rc == -1 and b"null" in ffi.lib.tfimm_hip_last_error()
