@@ -167,7 +167,7 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
     # The batch as two slices on PARALLEL branches of one HIP graph (engine/graph.py CapturedBranches: same kernels, bit-equal
     # results, launches of the two slices side by side).  "auto": both recordings are timed before the warm-up and the faster
     # one runs in the timed region; the choice and the other mode's time are reported (config.launch, single_branch_ms_per_step).
-    forked, single_ms, forked_ms = None, None, None
+    forked, single_ms, forked_ms, hybrid_cut = None, None, None, None
     n_br = 2 if branches == "auto" else int(branches)
     if captured is not None and n_br > 1 and batch >= 2 * n_br and prog.supports_branches():
         from tfimm.engine.graph import CapturedBranches
@@ -187,8 +187,25 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
                 torch.cuda.synchronize()
                 return (time.perf_counter() - t) / n * 1e3
             single_ms, forked_ms = _time(captured), _time(forked)
-            if branches == "auto" and forked_ms >= single_ms:
-                forked = None
+            if branches == "auto":
+                # ... and hybrids: branches for the first part of the program, the full batch for the rest (CapturedHybrid:
+                # ResNet-50's 14 x 14 / 7 x 7 stages are too small to split).  A few cut positions, the fastest recording wins.
+                from tfimm.engine.graph import CapturedHybrid
+                n_ops = len(prog.ops)
+                for frac in (0.5, 0.65, 0.8, 0.9):
+                    try:
+                        hyb = CapturedHybrid(prog, x, max(1, int(round(frac * n_ops))))
+                    except RuntimeError as e:
+                        print(f"warning: hybrid recording failed ({e})", file=sys.stderr)
+                        torch.cuda.synchronize()
+                        break
+                    t_h = _time(hyb)
+                    if t_h < forked_ms:
+                        forked, forked_ms, hybrid_cut = hyb, t_h, hyb.cut_op
+                    else:
+                        del hyb
+                if forked_ms >= single_ms:
+                    forked = None
 
     def step(events=None):
         if forked is not None and events is None:
@@ -248,7 +265,9 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
             s_["n"] += 1
             s_["flops"] += flops
     return dict(seconds=dt, ms_per_step=dt / steps * 1e3, kernels=stats, logits=logits, x=x, prog=prog,
-                graph=captured is not None, gathered=gathered, branches=(len(forked.plans) if forked is not None else 1),
+                graph=captured is not None, gathered=gathered, branches=(2 if forked is not None else 1),
+                hybrid_cut=(hybrid_cut if forked is not None and hybrid_cut is not None and getattr(forked, "cut_op", None) == hybrid_cut else None),
+                n_ops=len(prog.ops),
                 single_branch_ms=single_ms, forked_ms=forked_ms,
                 eager_ms_per_step=None if eager_dt is None else eager_dt / steps * 1e3)
 
@@ -552,7 +571,8 @@ def run_workload(name, args, world, rank, dist, steps, warmup, batch=0, micro_ba
         out = dict(value=round(total / ms * 1e3, 1), unit="images/sec", ms_per_step=round(ms, 4), per_gpu_batch=batch,
                    global_batch=total, per_rank_ms=per_rank, model=wl["model"], input_size=int(model.cfg.input_size[0]),
                    launch=("eager" if not r["graph"] else "hipGraph replay" if r["branches"] == 1 else
-                           f"hipGraph replay, {r['branches']} parallel branches of {batch // r['branches']} images"),
+                           f"hipGraph replay, {r['branches']} parallel branches of {batch // r['branches']} images" +
+                           (f" for ops 0..{r['hybrid_cut'] - 1} of {r['n_ops']}, the full batch for the rest" if r["hybrid_cut"] else "")),
                    branches=r["branches"],
                    single_branch_ms_per_step=None if r["single_branch_ms"] is None else round(r["single_branch_ms"], 4),
                    forked_ms_per_step=None if r["forked_ms"] is None else round(r["forked_ms"], 4),

@@ -202,6 +202,19 @@ class Program:
     def make_plan(self, batch: int, device: str = "cuda") -> "Plan":
         return Plan(self, batch, device)
 
+    def live_across(self, op_index: int) -> List[int]:
+        """Tensors written by ops [0, op_index) that ops [op_index, ...) still read (or that are program outputs)."""
+        written, needed = set(), set()
+        for i, op in enumerate(self.ops):
+            outs = ([op.output] if op.output is not None else []) + list(op.extra_outputs)
+            if i < op_index:
+                written.update(outs)
+            else:
+                needed.update(op.inputs)
+                needed.update(o for o in outs if o in written)        # ops that update an earlier tensor in place
+        keep = {t.id for t in self.tensors if t.keep}
+        return sorted(t for t in written if t in needed or t in keep)
+
     def supports_branches(self) -> bool:
         """False for programs with the talking-heads attention launch (CaiT).  tools/branch_hunt.py: next to launches of a
         second stream the H = 4 instance of that kernel (cait_xxs24 / xxs36) is not bit-reproducible -- alone it is, with any
@@ -963,12 +976,16 @@ class Builder:
 # Plan: a program bound to device buffers for one batch size
 # ---------------------------------------------------------------------------------------
 class Plan:
-    def __init__(self, prog: Program, batch: int, device: str = "cuda"):
+    def __init__(self, prog: Program, batch: int, device: str = "cuda", external: Optional[Dict[int, int]] = None):
         """``device="cpu"`` builds the same call list over host buffers; it can only be used
-        to inspect / marshal-check the plan (tests without a GPU) -- launching it fails."""
+        to inspect / marshal-check the plan (tests without a GPU) -- launching it fails.
+        ``external``: tensor id -> device address: those tensors live at that address instead of in this plan's slabs (the
+        branches of ``CapturedHybrid`` write what crosses the join straight into the full-batch plan's buffers)."""
         import torch
         from . import ffi
         self.ffi = ffi
+        self.external = dict(external or {})
+        self.op_call_start: List[int] = []      # first entry of ``calls`` of every op (CapturedHybrid cuts between ops)
         self.prog = prog
         self.batch = batch
         self.device = device
@@ -993,6 +1010,8 @@ class Plan:
 
     # pointers ----------------------------------------------------------------------------------
     def tptr(self, tid: int) -> int:
+        if tid in self.external:
+            return self.external[tid]
         return self.slabs[self.assign[tid]].data_ptr()
 
     def cptr(self, cid: Optional[int]) -> Optional[int]:
@@ -1016,6 +1035,7 @@ class Plan:
         for op in prog.ops:
             a = op.attrs
             k = op.kind
+            self.op_call_start.append(len(self.calls))
             if k == "cast_input":
                 out = self.tptr(op.output)
                 H, W, cin = prog.input_shape
@@ -1565,11 +1585,11 @@ class Plan:
         in_dtype = 1 if x_dev.dtype == torch.bfloat16 else 0
         return self._input_call[0](x_dev.data_ptr(), in_dtype, *self._input_call[1], st)
 
-    def run(self, x_dev, stream_ptr: Optional[int] = None, norm=None):
+    def run(self, x_dev, stream_ptr: Optional[int] = None, norm=None, lo: int = 0, hi: Optional[int] = None):
         """Enqueue the whole program on the current torch stream.  ``x_dev``: contiguous cuda
         tensor (B, H, W, C) float32 or bfloat16 -- or uint8 with ``norm = (mean, std)`` (one float per
         channel): the model's preprocessing then runs inside the input conversion
-        (tfimm_hip_preprocess_input)."""
+        (tfimm_hip_preprocess_input).  ``lo`` / ``hi``: only entries [lo, hi) of ``calls`` (CapturedHybrid)."""
         import torch
         ffi = self.ffi
         if stream_ptr is None:
@@ -1579,7 +1599,9 @@ class Plan:
         # TFIMM_ROCTX=1: one roctx range per launch, named "<index> <op kind> <reference file:line>" -- rocprofv3
         # --marker-trace then attributes kernel time to the reference call site each launch replaces
         marks = self._roctx_labels() if os.environ.get("TFIMM_ROCTX", "0") == "1" else None
-        for i, (fn, args) in enumerate(self.calls):
+        hi = len(self.calls) if hi is None else hi
+        for i in range(lo, hi):
+            fn, args = self.calls[i]
             if marks is not None:
                 ffi.roctx_push(marks[i])
             try:
@@ -1672,6 +1694,60 @@ class CapturedBranches:
         """The program output ``t`` of the whole batch (the branches' slices concatenated)."""
         import torch
         return torch.cat([p.tensor_view(t) for p in self.plans], dim=0)
+
+
+class CapturedHybrid:
+    """Parallel branches for the FIRST ops of the program only: two half-batch plans run ops [0, cut_op) side by side, the
+    full-batch plan runs the rest.  Where a forward ends in launches too small to split (ResNet-50: the 14 x 14 and 7 x 7 stages
+    lose 2 - 20 % as two half-batch launches, the 56 x 56 and 28 x 28 stages win 7 - 22 %: tools/stage_fork_probe.py) this keeps
+    the gain of the early stages without the loss of the late ones.  What crosses the join lives in the FULL plan's buffers: the
+    branches are built with those tensors ``external`` (their slice of the full tensor), so the join is free.  One
+    ``hipGraphLaunch``, bit-equal results (tests/test_gpu_branches.py)."""
+
+    def __init__(self, prog: "Program", x_dev, cut_op: int, norm=None):
+        import torch
+        B = x_dev.shape[0]
+        assert 0 < cut_op <= len(prog.ops) and B >= 2
+        self.full = Plan(prog, B)
+        nb = branch_sizes(B, 2)
+        live = prog.live_across(cut_op) if cut_op < len(prog.ops) else [t.id for t in prog.tensors if t.keep and t.dtype != "raw"]
+        live = [t for t in live if prog.tensors[t].dtype != "raw"]
+        self.halves, lo = [], 0
+        for n_img in nb:
+            ext = {t: self.full.tptr(t) + lo * prog.tensors[t].bytes_per_image for t in live}
+            self.halves.append(Plan(prog, n_img, external=ext))
+            lo += n_img
+        self.static_input = x_dev
+        self.cut_op = cut_op
+        self.slices = [(0, nb[0]), (nb[0], B)]
+        cut = self.full.op_call_start[cut_op] if cut_op < len(prog.ops) else len(self.full.calls)
+        assert all(h.op_call_start == self.full.op_call_start for h in self.halves)
+        self.cut_call = cut
+
+        def forward():
+            main = torch.cuda.current_stream()
+            self.side.wait_stream(main)
+            (a0, a1), (b0, b1) = self.slices
+            self.halves[0].run(x_dev[a0:a1], norm=norm, hi=cut)
+            with torch.cuda.stream(self.side):
+                self.halves[1].run(x_dev[b0:b1], norm=norm, hi=cut)
+            main.wait_stream(self.side)
+            if cut < len(self.full.calls):
+                self.full.run(x_dev, norm=norm, lo=cut)
+
+        self.side = torch.cuda.Stream()
+        self.full.run(x_dev, norm=norm)          # lazy host-side initialisation of every launch, outside the recording
+        forward()
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            forward()
+
+    def replay(self):
+        self.graph.replay()
+
+    def output(self, t: "TRef"):
+        return self.full.tensor_view(t)
 
 
 def _hip_memset_async(ptr: int, nbytes: int, stream_ptr: int) -> int:

@@ -62,3 +62,32 @@ def test_talking_heads_programs_keep_one_branch():
     runs = [model(x).numpy() for _ in range(3)]
     assert all(np.array_equal(r, want) for r in runs)
     assert not [k for k in model._plans if "branches" in k]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,batch", [("resnet50", 8), ("swin_tiny_patch4_window7_224", 6), ("efficientnet_b0", 7),
+                                        ("convnext_test_model", 6), ("seresnet_test_model", 5)])
+def test_hybrid_recordings_reproduce_the_single_plan_bit_for_bit(name, batch):
+    """CapturedHybrid: two half-batch branches for ops [0, cut), the full-batch plan for the rest, what crosses the join
+    written by the branches straight into the full plan's buffers -- every cut position tried must give the single plan's bits."""
+    import torch
+
+    import model_checks as mc
+    from tfimm.engine.graph import CapturedHybrid
+    model = tfimm.create_model(name)
+    model.set_weights(synthetic_weights(model, 2021))
+    x = torch.from_numpy(mc.make_input(model.cfg, batch)).cuda().contiguous()
+    prog = model.program()
+    plan = prog.make_plan(batch)
+    plan.run(x)
+    torch.cuda.synchronize()
+    out_t = prog.outputs["logits"]
+    want = plan.tensor_view(out_t).float().cpu().numpy().copy()
+    n = len(prog.ops)
+    for cut in sorted({1, 2, n // 3, n // 2, (2 * n) // 3, n - 1, n}):
+        h = CapturedHybrid(prog, x, cut)
+        for _ in range(2):
+            h.replay()
+        torch.cuda.synchronize()
+        got = h.output(out_t).float().cpu().numpy()
+        assert np.array_equal(got, want), (name, cut, float(np.abs(got - want).max()))
