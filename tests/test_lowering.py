@@ -304,3 +304,29 @@ def test_mlp_fused_operands():
     assert sorted(order) == list(range(h))
     np.testing.assert_allclose(pack.bf16_bits_to_f32(w2), ((k2 * ls[None, :])[order]).T, rtol=2 ** -8)
     np.testing.assert_allclose(b2f, b2 * ls, rtol=1e-6)
+
+
+def test_live_tensors_across_a_cut_and_branch_support():
+    """Program.live_across(i): what ops [0, i) wrote and ops [i, ...) still need -- the tensors the branches of a hybrid
+    recording write into the full plan's buffers.  A ResNet block boundary carries exactly the block output; inside a
+    bottleneck the shortcut is live as well.  Programs with the talking-heads launch do not take branches."""
+    kinds, prog = _kinds("resnet50")
+    ops = prog.ops
+    written_before = set()
+    for i, op in enumerate(ops):
+        if i > 0:
+            live = prog.live_across(i)
+            assert live and set(live) <= written_before
+            needed = {t for o in ops[i:] for t in o.inputs}
+            assert all(t in needed or prog.tensors[t].keep for t in live)
+        written_before.update(([op.output] if op.output is not None else []) + list(op.extra_outputs))
+    # behind the first fused bottleneck tail (stem_pool, conv1, conv_chain): one tensor, 256 channels at 56 x 56
+    i = kinds.index("conv_chain") + 1
+    (t,) = prog.live_across(i)
+    assert (prog.tensors[t].C, prog.tensors[t].rows) == (256, 56 * 56)
+    # between conv1 and the tail of the SECOND block: conv1's output and the block input (the shortcut)
+    j = [k for k, kd in enumerate(kinds) if kd == "conv_chain"][1]
+    assert sorted(prog.tensors[t].C for t in prog.live_across(j)) == [64, 256]
+    assert prog.supports_branches()
+    _, cait = _kinds("cait_test_model")
+    assert not cait.supports_branches()
