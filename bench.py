@@ -173,8 +173,9 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
         from tfimm.engine.graph import CapturedBranches
         try:
             forked = CapturedBranches(prog.make_branches(batch, n_br), x)
-        except RuntimeError as e:
-            print(f"warning: branch recording failed ({e}); one branch", file=sys.stderr)
+        except Exception as e:      # a recording that cannot be made must not cost the measurement: one branch
+            print(f"warning: branch recording failed ({type(e).__name__}: {e}); one branch", file=sys.stderr)
+            forked = None
             torch.cuda.synchronize()
         if forked is not None:
             def _time(g, n=5):
@@ -195,8 +196,8 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
                 for frac in (0.5, 0.65, 0.8, 0.9):
                     try:
                         hyb = CapturedHybrid(prog, x, max(1, int(round(frac * n_ops))))
-                    except RuntimeError as e:
-                        print(f"warning: hybrid recording failed ({e})", file=sys.stderr)
+                    except Exception as e:
+                        print(f"warning: hybrid recording failed ({type(e).__name__}: {e})", file=sys.stderr)
                         torch.cuda.synchronize()
                         break
                     t_h = _time(hyb)
