@@ -26,6 +26,7 @@
 //   * the output accumulators START as residual + b2 (the residual rows are requested at the top of the tile and
 //     unpacked just before the first GEMM 2: their latency is behind a whole group of work), so the epilogue is 16 stores.
 // The intermediate is rounded to bf16 exactly once, like the two-launch path rounds the tensor it stores.
+#include <algorithm>
 #include "gemm_stream_kernel.h"
 
 using namespace tfimm_gemm;
@@ -490,8 +491,24 @@ extern "C" int tfimm_hip_mlp_fused(const tfimm_mlp_desc* dp, void* stream) {
   if (((uintptr_t)d.x | (uintptr_t)d.w1 | (uintptr_t)d.b1 | (uintptr_t)d.w2 | (uintptr_t)d.b2 | (uintptr_t)d.residual |
        (uintptr_t)d.out) & 15)
     TFIMM_FAIL(TFIMM_EINVAL, "mlp_fused: pointers must be 16-byte aligned");
+  // a buffer descriptor addresses 2 GiB: larger tensors (Swin-B stage 1 from batch 2675 on) run as chunks of whole 256-row tiles
+  // -- rows are independent.  TFIMM_MLP_LIMIT (bytes) lowers the threshold: a test hook, read once.
+  static const int64_t limit = getenv("TFIMM_MLP_LIMIT") ? atoll(getenv("TFIMM_MLP_LIMIT")) : 0x7fffff00LL;
   const int64_t act_bytes = d.M * d.C * 2;
-  if (act_bytes > 0x7fffff00LL) TFIMM_FAIL(TFIMM_EUNSUP, "mlp_fused: a tensor exceeds the 2 GiB a buffer descriptor addresses");
+  if (act_bytes > limit) {
+    const int64_t rows_max = limit / (d.C * 2) / 256 * 256;
+    if (rows_max <= 0) TFIMM_FAIL(TFIMM_EINVAL, "mlp_fused: TFIMM_MLP_LIMIT below one tile");
+    for (int64_t m = 0; m < d.M; m += rows_max) {
+      tfimm_mlp_desc sub = d;
+      const int64_t off = m * d.C * 2;
+      sub.x = (const char*)d.x + off;
+      sub.residual = (const char*)d.residual + off;
+      sub.out = (char*)d.out + off;
+      sub.M = std::min<int64_t>(rows_max, d.M - m);
+      if (int rc = tfimm_hip_mlp_fused(&sub, stream)) return rc;
+    }
+    return 0;
+  }
   MlpArgs a;
   a.x = (const bf16_t*)d.x; a.w1 = (const bf16_t*)d.w1; a.b1 = d.b1; a.w2 = (const bf16_t*)d.w2; a.b2 = d.b2;
   a.residual = (const bf16_t*)d.residual; a.out = (bf16_t*)d.out;

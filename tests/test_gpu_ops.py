@@ -56,3 +56,20 @@ def test_two_ktile_tiles_of_the_duo_kernel_are_reproducible(K, N, act, residual)
         H.sync()
         bad = int((out.view(torch.int16) != ref).sum().item())
         assert bad == 0, f"launch {run}: {bad} elements differ from the stream tile's result"
+
+
+def test_mlp_fused_splits_oversize_tensors_into_row_chunks():
+    """tfimm_hip_mlp_fused runs tensors beyond the 2 GiB of a buffer descriptor (Swin-B stage 1 from batch 2675 on) as chunks of
+    whole tiles.  TFIMM_MLP_LIMIT lowers that threshold (read once per process, hence the subprocess): 1 MiB = 4096 rows per
+    chunk, i.e. 3 ... 18 launches for these cases -- same oracle, same tolerance."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path[:0] = [%r, %r, %r]; import hip_checks\n"
+            "for n in ('mlp_fused_layerscale_residual', 'mlp_fused_multiround_70001', 'mlp_fused_swin_stage1_b8'):\n"
+            "    e, t = hip_checks.run_case(n); print(n, e, t); assert e <= t, (n, e, t)\n"
+            % (root, os.path.join(root, "tensorflow-image-models_amd"), os.path.join(root, "tests")))
+    env = dict(os.environ, TFIMM_MLP_LIMIT=str(1 << 20))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
