@@ -207,6 +207,14 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
                         del hyb
                 if forked_ms >= single_ms:
                     forked = None
+    # the recording that will be timed must give the bits of the single-branch recording (checked once, before the warm-up)
+    forked_bit_equal = None
+    if forked is not None:
+        captured.replay()
+        one = plans[batch].tensor_view(out_t).view(batch, out_t.C).float().clone()
+        forked.replay()
+        forked_bit_equal = bool(torch.equal(one, forked.output(out_t).view(batch, out_t.C).float()))
+        torch.cuda.synchronize()
 
     def step(events=None):
         if forked is not None and events is None:
@@ -239,14 +247,35 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]   # per-step durations for the median: events on
+    t0 = time.perf_counter()                                                   # the launch stream, no host synchronisation
+    marks[0].record()
+    for i in range(steps):
         step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    median_ms = per_step[steps // 2] if steps % 2 else 0.5 * (per_step[steps // 2 - 1] + per_step[steps // 2])
+    # the exchange step really delivered this rank's logits (and, world = 1, nothing else): bit for bit
+    gather_bit_equal = None
+    if dist is not None:
+        rk = dist.get_rank()
+        gather_bit_equal = bool(torch.equal(gathered[rk * batch:(rk + 1) * batch], logits))
+    # the other launch mode under the SAME protocol (warm-up, K steps between synchronisations), so that kernel changes stay
+    # visible round over round whichever mode wins on a box
+    if forked is not None and captured is not None:
+        for _ in range(warmup):
+            captured.replay()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(steps):
+            captured.replay()
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - t2) / steps * 1e3
     # per-kernel durations: the same K steps again, launched eagerly with a HIP event pair (on the launch stream)
     # around every launch of the conv / linear / attention families -- events cannot be read back from a graph replay
     events = [] if kernel_events else None
@@ -265,7 +294,8 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
             s_["ms"] += e0.elapsed_time(e1)
             s_["n"] += 1
             s_["flops"] += flops
-    return dict(seconds=dt, ms_per_step=dt / steps * 1e3, kernels=stats, logits=logits, x=x, prog=prog,
+    return dict(seconds=dt, ms_per_step=dt / steps * 1e3, median_ms_per_step=median_ms, gather_bit_equal=gather_bit_equal,
+                forked_bit_equal=forked_bit_equal, kernels=stats, logits=logits, x=x, prog=prog,
                 graph=captured is not None, gathered=gathered, branches=(2 if forked is not None else 1),
                 hybrid_cut=(hybrid_cut if forked is not None and hybrid_cut is not None and getattr(forked, "cut_op", None) == hybrid_cut else None),
                 n_ops=len(prog.ops),
@@ -569,7 +599,14 @@ def run_workload(name, args, world, rank, dist, steps, warmup, batch=0, micro_ba
         prog = r["prog"]
         flops_img = prog.flops_per_image()
         total = batch * world
-        out = dict(value=round(total / ms * 1e3, 1), unit="images/sec", ms_per_step=round(ms, 4), per_gpu_batch=batch,
+        rl = roofline_of(name, wl, r, steps, batch)
+        if rl is not None and rl.get("algorithmic_bytes_per_step"):
+            # the timed region's own figure: algorithmic bytes of a step over ms_per_step (parallel branches included) --
+            # `frac` is the kernels by themselves (one branch, launch by launch)
+            rl["frac_timed_mode"] = round(rl["algorithmic_bytes_per_step"] / (ms * 1e-3) / 1e9 / rl["peak"], 4)
+        out = dict(value=round(total / ms * 1e3, 1), unit="images/sec", ms_per_step=round(ms, 4),
+                   median_ms_per_step=round(r["median_ms_per_step"], 4), gather_bit_equal=r["gather_bit_equal"],
+                   forked_bit_equal_to_single=r["forked_bit_equal"], per_gpu_batch=batch,
                    global_batch=total, per_rank_ms=per_rank, model=wl["model"], input_size=int(model.cfg.input_size[0]),
                    launch=("eager" if not r["graph"] else "hipGraph replay" if r["branches"] == 1 else
                            f"hipGraph replay, {r['branches']} parallel branches of {batch // r['branches']} images" +
@@ -580,7 +617,7 @@ def run_workload(name, args, world, rank, dist, steps, warmup, batch=0, micro_ba
                    gflops_per_image=round(flops_img / 1e9, 3),
                    model_tflops=round(flops_img * total / ms / 1e9, 1),
                    mfma_frac_whole_step=round(flops_img * batch / ms / 1e9 / 2500.0, 4),
-                   roofline=roofline_of(name, wl, r, steps, batch))
+                   roofline=rl)
         if with_cpu:
             cpu, xs, ys, fs = cpu_baseline(model, wl["model"])
             out["cpu_baseline"] = cpu
@@ -644,7 +681,8 @@ def main():
         m = main_r
         line = {
             "metric": "images/sec (fwd, bf16)", "value": m["value"], "unit": "images/sec", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"], "higher_is_better": True,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
+            "median_ms_per_step": m["median_ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{m['model']} @{m['input_size']} fwd", "per_gpu_batch": m["per_gpu_batch"],
                        "global_batch": m["global_batch"], "micro_batch": args.micro_batch or m["per_gpu_batch"],
@@ -654,7 +692,9 @@ def main():
                                                     "external" if launched else "in-process"),
                        "weights": "random-init (synthetic generator, seed 2021)", "launch": m["launch"],
                        "branches": m["branches"], "single_branch_ms_per_step": m["single_branch_ms_per_step"],
-                       "forked_ms_per_step": m["forked_ms_per_step"], "gflops_per_image": m["gflops_per_image"]},
+                       "forked_ms_per_step": m["forked_ms_per_step"], "gflops_per_image": m["gflops_per_image"],
+                       "forked_bit_equal_to_single": m["forked_bit_equal_to_single"],
+                       "gathered_logits_bit_equal_to_local": m["gather_bit_equal"]},
             "per_rank_ms": m["per_rank_ms"], "model_tflops": m["model_tflops"],
             "roofline": m["roofline"], "cpu_baseline": m.get("cpu_baseline"), "parity_vs_oracle": m.get("parity_vs_oracle"),
             "headline": {k: (v["value"] if v and "value" in v else None)

@@ -264,8 +264,8 @@ typedef struct tfimm_tha_desc {
   int32_t batch, n_tokens, heads, hd;
   float scale;
   const float* proj_dev;    /* optional DEVICE fp32 [proj_l_w | proj_l_b | proj_w_w | proj_w_b] (2 * (heads^2 + heads) values): the
-                               MFMA kernel then takes the mixing layers from there instead of its argument segment -- required
-                               for bit-reproducible results when launches of another stream run side by side */
+                               MFMA kernel then takes the mixing layers from there instead of its argument segment (what
+                               plans do; results are the same either way) */
 } tfimm_tha_desc;
 
 TFIMM_API int tfimm_hip_talking_heads_attention(const tfimm_tha_desc* d, void* stream);

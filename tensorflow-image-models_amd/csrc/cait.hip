@@ -62,6 +62,28 @@ struct ThaArgs {
 
 constexpr int THA_KB = 32;        // keys staged per step
 
+#ifdef TFIMM_THA_DBG
+// Probe build only (tools/probes/build_tha_dbg.sh; profiles/NOTES_r04.md section 1): integrity checks of everything the
+// workgroup keeps in LDS, 16 words per workgroup:
+//   0 HW_ID  1 LDS_ALLOC  2 GPR_ALLOC  3 XCC_ID  4 K/V chunk staged by ANOTHER wave != its source, right behind the barrier
+//   5 own source chunk loaded a second time != first load  6 Wm  7 zero pads of Ks  8 Qs vs global  9 own staged chunk changed
+//   while the block was consumed, or poisoned columns no fragment read touches (Ks / Qs columns >= H*HP, Vs columns >= D) changed
+//   10 St vs the registers that wrote it
+//   11 first bad LDS byte offset + 1   12/13 s_memrealtime at entry / exit (low words)   14/15 the first 8 bytes of the bad 16-byte slot
+__device__ unsigned tha_dbg_buf[16384 * 16];
+__device__ float tha_dbg_st[1024 * 512];      // the softmax statistics (St) of workgroups 0 .. 1023 as pass 2 reads them
+__device__ unsigned tha_dbg_ck[1024 * 4];
+__device__ float tha_dbg_run[256 * 2048];     // workgroups 0 .. 255: every lane's (m_run, l_run) per mixed head when the key loop of pass 1 ends     // wrap-around word sums of everything staged: K in pass 1, K in pass 2, V in pass 2
+__device__ __forceinline__ uint4 tha_vload(const bf16_t* p) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u4v;
+  const u4v v = *reinterpret_cast<const volatile u4v*>(p);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+#define THA_DBG_ONLY(...) __VA_ARGS__
+#else
+#define THA_DBG_ONLY(...)
+#endif
+
 template <int H, int HG, int DT, bool QLDS>
 __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p, const ThaWeights w) {
   constexpr int HD = DT * 16;
@@ -75,9 +97,15 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p, const ThaWeig
   const int D = p.dmodel;
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_tha);                     // [THA_KB][kstr], heads at stride HP
   bf16_t* Vs = Ks + THA_KB * p.kstr;                                     // [THA_KB][vstr], row-major V
-  float* St = reinterpret_cast<float*>(Vs + THA_KB * p.vstr);            // [4 waves][H][16][2]
-  float* Wm = St + 4 * H * 16 * 2;                                       // wl [H][H], bl [H], ww [H][H], bw [H]
-  bf16_t* Qs = reinterpret_cast<bf16_t*>(Wm + (2 * (H * H + H) + 3) / 4 * 4);   // [64][kstr] (q_in_lds)
+  // Everything the packed fp32 arithmetic below takes from LDS is stored TWICE, as a (v, v) pair, and used as a whole pair.
+  // With one copy hipcc loads two neighbours with one ds_read2_b32 and picks the second with an operand select
+  // (v_pk_fma_f32 ... op_sel:[0,1,0]) -- and on gfx950 a packed fp32 operation whose LOW result takes the HIGH half of a
+  // source returns the product of the wrong half in lanes 48..63 whenever a wave of another workgroup issues MFMAs on the same
+  // SIMD (tools/tha_coresident_probe.py ldsret reproduces it on a six-instruction kernel; profiles/NOTES_r04.md section 1).
+  // tools/isa_lint.py keeps such instructions out of every product kernel.
+  float* St = reinterpret_cast<float*>(Vs + THA_KB * p.vstr);            // [4 waves][H][16][4]: (max, max, 1 / sum, 1 / sum)
+  tfimm_f32x2* Wm = reinterpret_cast<tfimm_f32x2*>(St + 4 * H * 16 * 4); // wl [H][H], bl [H], ww [H][H], bw [H], every value as a pair
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(Wm + 2 * (H * H + H));          // [64][kstr] (q_in_lds)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -87,23 +115,47 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p, const ThaWeig
   const int q = qc * 64 + wave * 16 + l15;
   const bool q_ok = q < p.n;
   const int CH = D / 8;             // 16-byte chunks per token row of one of q / k / v
+#ifdef TFIMM_THA_DBG
+  unsigned* const dbg = tha_dbg_buf + (size_t)(blockIdx.x < 16384 ? blockIdx.x : 16383) * 16;
+  const int lds_total = (int)(reinterpret_cast<char*>(Qs) - smem_tha) + (QLDS ? 64 * p.kstr * 2 : 0);
+  for (int i = tid; i < lds_total / 4; i += 256) reinterpret_cast<unsigned*>(smem_tha)[i] = 0xDEADBEEFu;
+  if (tid == 0) {
+    dbg[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    dbg[1] = __builtin_amdgcn_s_getreg((31 << 11) | 6);
+    dbg[2] = __builtin_amdgcn_s_getreg((31 << 11) | 5);
+    dbg[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    for (int i = 4; i < 12; ++i) dbg[i] = 0;
+    if (blockIdx.x < 1024) for (int i = 0; i < 4; ++i) tha_dbg_ck[blockIdx.x * 4 + i] = 0;
+    dbg[12] = (unsigned)__builtin_amdgcn_s_memrealtime();
+  }
+  __syncthreads();
+  auto dbg_bad = [&](int what, const void* where) {
+    atomicAdd(&dbg[what], 1u);
+    if (atomicCAS(&dbg[11], 0u, (unsigned)(reinterpret_cast<const char*>(where) - smem_tha) + 1u) == 0u) {
+      const unsigned* w4 = reinterpret_cast<const unsigned*>((size_t)where & ~(size_t)15);   // the 16 bytes around it, as they are now
+      dbg[14] = w4[0]; dbg[15] = w4[1];
+    }
+  };
+  constexpr int DBG_NC = (H * HD / 8 + 7) / 8;
+  uint4 dbg_k[DBG_NC], dbg_v[DBG_NC];
+  bool dbg_have = false, dbg_with_v = false;
+#endif
 
   if (p.wdev) {
-    // from device memory, in Wm's own order.  (From the argument segment -- the `else` below -- the result of this kernel
-    // stopped being reproducible as soon as launches of a second stream ran next to it: tools/branch_hunt.py, CaiT under
-    // parallel branches; a 2 KiB by-value struct read with vector loads.  Plans always pass the device copy.)
+    // from device memory, in Wm's own order (plans pass the device copy: no 2 KiB by-value struct per launch)
     for (int id = tid; id < 2 * (H * H + H); id += 256) {
       const float v = p.wdev[id];
-      Wm[id] = (id >= H * H && id < H * H + H) ? v * LOG2E : v;
+      const float e = (id >= H * H && id < H * H + H) ? v * LOG2E : v;
+      Wm[id] = tfimm_f32x2{e, e};
     }
   } else {
     for (int id = tid; id < H * H; id += 256) {
-      Wm[id] = w.wl[id];
-      Wm[H * H + H + id] = w.ww[id];
+      Wm[id] = tfimm_f32x2{w.wl[id], w.wl[id]};
+      Wm[H * H + H + id] = tfimm_f32x2{w.ww[id], w.ww[id]};
     }
     if (tid < H) {
-      Wm[H * H + tid] = w.bl[tid] * LOG2E;
-      Wm[2 * H * H + H + tid] = w.bw[tid];
+      Wm[H * H + tid] = tfimm_f32x2{w.bl[tid] * LOG2E, w.bl[tid] * LOG2E};
+      Wm[2 * H * H + H + tid] = tfimm_f32x2{w.bw[tid], w.bw[tid]};
     }
   }
   // staging map (no divisions): 8 threads per row, thread (row = tid >> 3) walks chunks (tid & 7) + 8 j;
@@ -137,7 +189,7 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p, const ThaWeig
   // key loop.  Offsets, not pointers: an opaque POINTER loses its address space and turns every read
   // into a flat load)
   int qs_off = (wave * 16 + l15) * p.kstr;
-  int st_off = (wave * H * 16 + l15) * 2;
+  int st_off = (wave * H * 16 + l15) * 4;
   int wm_off = 0;
   // Q fragment of head h, k-step ks for this lane's query: d = ks*32 + g*8 .. +8 (zero beyond HD)
   auto q_frag = [&](int h, int ks) -> bf16x8 {
@@ -152,6 +204,22 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p, const ThaWeig
   };
 
   auto stage = [&](int kb, bool with_v) {
+#ifdef TFIMM_THA_DBG
+    if (dbg_have) {   // the block this thread staged last time, now that every fragment read of it is over
+      int j = 0;
+      for (int c = sc0; c < CH; c += 8, ++j) {
+        const int h = c / CPH;
+        const uint4* kq = reinterpret_cast<const uint4*>(&Ks[srow * p.kstr + h * HP + (c - h * CPH) * 8]);
+        const uint4 a = *kq;
+        if (a.x != dbg_k[j].x || a.y != dbg_k[j].y || a.z != dbg_k[j].z || a.w != dbg_k[j].w) dbg_bad(9, kq);
+        if (dbg_with_v) {
+          const uint4* vq = reinterpret_cast<const uint4*>(&Vs[srow * p.vstr + c * 8]);
+          const uint4 b = *vq;
+          if (b.x != dbg_v[j].x || b.y != dbg_v[j].y || b.z != dbg_v[j].z || b.w != dbg_v[j].w) dbg_bad(9, vq);
+        }
+      }
+    }
+#endif
     __syncthreads();   // previous block fully consumed (and Qs / Wm written, first time)
     const int t = kb + srow;
     const bf16_t* kp = p.qkv + (row0 + (t < p.n ? t : 0)) * p.ld + D;
@@ -164,19 +232,61 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p, const ThaWeig
       const int h = c / CPH;
       *reinterpret_cast<uint4*>(&Ks[srow * p.kstr + h * HP + (c - h * CPH) * 8]) = ku;
       if (with_v) *reinterpret_cast<uint4*>(&Vs[srow * p.vstr + c * 8]) = vu;
+      THA_DBG_ONLY(dbg_k[(c - sc0) >> 3] = ku; dbg_v[(c - sc0) >> 3] = vu;
+                   if (blockIdx.x < 1024) {
+                     atomicAdd(&tha_dbg_ck[blockIdx.x * 4 + (with_v ? 1 : 0)], ku.x + ku.y + ku.z + ku.w);
+                     if (with_v) atomicAdd(&tha_dbg_ck[blockIdx.x * 4 + 2], vu.x + vu.y + vu.z + vu.w);
+                   })
     }
     __syncthreads();
+#ifdef TFIMM_THA_DBG
+    dbg_have = true; dbg_with_v = with_v;
+    {
+      // (4) what ANOTHER wave staged (the thread 64 further on), right behind the barrier, against a fresh load of its source:
+      //     a barrier that lets this wave through early, or LDS writes that are not visible yet, show here
+      // (5) this thread's own source chunks loaded a second time against the registers of the first load
+      const int orow = ((tid + 64) & 255) >> 3;
+      const int ot = kb + orow;
+      const bf16_t* okp = p.qkv + (row0 + (ot < p.n ? ot : 0)) * p.ld + D;
+      int j = 0;
+      for (int c = sc0; c < CH; c += 8, ++j) {
+        const int h = c / CPH;
+        uint4 eku = make_uint4(0u, 0u, 0u, 0u), evu = eku, rku = eku, rvu = eku;
+        if (ot < p.n) {
+          eku = tha_vload(okp + c * 8);
+          if (with_v) evu = tha_vload(okp + D + c * 8);
+        }
+        if (t < p.n) {
+          rku = tha_vload(kp + c * 8);
+          if (with_v) rvu = tha_vload(kp + D + c * 8);
+        }
+        const uint4* kq = reinterpret_cast<const uint4*>(&Ks[orow * p.kstr + h * HP + (c - h * CPH) * 8]);
+        const uint4 a = *kq;
+        if (a.x != eku.x || a.y != eku.y || a.z != eku.z || a.w != eku.w) dbg_bad(4, kq);
+        if (rku.x != dbg_k[j].x || rku.y != dbg_k[j].y || rku.z != dbg_k[j].z || rku.w != dbg_k[j].w) dbg_bad(5, kq);
+        if (with_v) {
+          const uint4* vq = reinterpret_cast<const uint4*>(&Vs[orow * p.vstr + c * 8]);
+          const uint4 b = *vq;
+          if (b.x != evu.x || b.y != evu.y || b.z != evu.z || b.w != evu.w) dbg_bad(4, vq);
+          if (rvu.x != dbg_v[j].x || rvu.y != dbg_v[j].y || rvu.z != dbg_v[j].z || rvu.w != dbg_v[j].w) dbg_bad(5, vq);
+        }
+      }
+    }
+#endif
   };
 
   // mixed logits (log2 units) of key tile t of the staged block, all H mixed heads
-  const float cs = p.scale * LOG2E;
-  auto logits = [&](int kb, int t, f32x4* mixed) __attribute__((always_inline)) {
+  tfimm_f32x2 cs2 = {p.scale * LOG2E, p.scale * LOG2E};
+  asm volatile("" : "+v"(cs2));      // a real register pair (no operand select on a scalar)
+  // mixed[hp] = (lo, hi): the logits of keys 4g, 4g+1 and of keys 4g+2, 4g+3
+  auto logits = [&](int kb, int t, tfimm_f32x2 (*mixed)[2]) __attribute__((always_inline)) {
     asm volatile("" : "+v"(qs_off), "+v"(st_off), "+v"(wm_off));
-    const float* wm = Wm + wm_off;
+    const tfimm_f32x2* wm = Wm + wm_off;
 #pragma unroll
     for (int hp = 0; hp < H; ++hp) {
-      const float b = wm[H * H + hp];
-      mixed[hp] = (f32x4){b, b, b, b};
+      const tfimm_f32x2 b = wm[H * H + hp];
+      mixed[hp][0] = b;
+      mixed[hp][1] = b;
     }
     // fragments of head h + 1 are requested before head h is multiplied (one head of lookahead hides
     // the LDS latency); the scheduling barrier keeps hipcc from hoisting ALL heads' fragments to the
@@ -197,9 +307,13 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p, const ThaWeig
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[h & 1][ks], qf[h & 1][ks], acc, 0, 0, 0);
-      acc *= cs;
+      const tfimm_f32x2 a_lo = tfimm_f32x2{acc[0], acc[1]} * cs2, a_hi = tfimm_f32x2{acc[2], acc[3]} * cs2;
 #pragma unroll
-      for (int hp = 0; hp < H; ++hp) mixed[hp] += wm[h * H + hp] * acc;
+      for (int hp = 0; hp < H; ++hp) {
+        const tfimm_f32x2 w2 = wm[h * H + hp];
+        mixed[hp][0] = __builtin_elementwise_fma(w2, a_lo, mixed[hp][0]);
+        mixed[hp][1] = __builtin_elementwise_fma(w2, a_hi, mixed[hp][1]);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (kb + THA_KB > p.n) {   // last block: keys beyond the sequence take no part in the softmax
@@ -207,11 +321,12 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p, const ThaWeig
       for (int r = 0; r < 4; ++r)
         if (kb + t * 16 + g * 4 + r >= p.n) {
 #pragma unroll
-          for (int hp = 0; hp < H; ++hp) mixed[hp][r] = -1e30f;
+          for (int hp = 0; hp < H; ++hp) mixed[hp][r >> 1][r & 1] = -1e30f;
         }
     }
   };
 
+  THA_DBG_ONLY(float dbg_st[H][2];)
   // ---- pass 1: max / sum of every (mixed head, query), over this lane's keys first
   {
     float m_run[H], l_run[H];
@@ -221,11 +336,11 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p, const ThaWeig
       stage(kb, false);
 #pragma unroll 1
       for (int t = 0; t < THA_KB / 16; ++t) {
-        f32x4 mixed[H];
+        tfimm_f32x2 mixed[H][2];
         logits(kb, t, mixed);
 #pragma unroll
         for (int hp = 0; hp < H; ++hp) {
-          const f32x4 v = mixed[hp];
+          const f32x4 v = {mixed[hp][0][0], mixed[hp][0][1], mixed[hp][1][0], mixed[hp][1][1]};
           const float m_new = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), m_run[hp]);
           l_run[hp] = l_run[hp] * __builtin_amdgcn_exp2f(m_run[hp] - m_new) + __builtin_amdgcn_exp2f(v[0] - m_new) +
                       __builtin_amdgcn_exp2f(v[1] - m_new) + __builtin_amdgcn_exp2f(v[2] - m_new) +
@@ -234,6 +349,9 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p, const ThaWeig
         }
       }
     }
+    THA_DBG_ONLY(if (blockIdx.x < 256) for (int hp = 0; hp < H; ++hp) {
+                   tha_dbg_run[blockIdx.x * 2048 + (tid * H + hp) * 2] = m_run[hp];
+                   tha_dbg_run[blockIdx.x * 2048 + (tid * H + hp) * 2 + 1] = l_run[hp]; })
     // combine the four key groups (g) of a query, publish (max, 1 / sum)
 #pragma unroll
     for (int hp = 0; hp < H; ++hp) {
@@ -242,10 +360,18 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p, const ThaWeig
       float l = l_run[hp] * __builtin_amdgcn_exp2f(m_run[hp] - m);
       l += __shfl_xor(l, 16, 64);
       l += __shfl_xor(l, 32, 64);
+      // The sums must be COMPLETE before the wave narrows EXEC for the store below.  hipcc sinks the last add into the
+      // `if (g == 0)` block and leaves its ds_bpermute_b32 in flight across the s_and_saveexec; when the LDS pipe is
+      // backed up (a GEMM workgroup of another stream on the same CU) the shuffle then executes under the NARROWED mask,
+      // lanes whose partner is disabled receive 0, and a query's 1 / sum misses two of its four key groups -- the round-3
+      // "co-residency defect" (profiles/NOTES_r04.md section 1; tools/tha_coresident_probe.py bperm).  Naming the values as
+      // asm operands forces the add, and with it the s_waitcnt lgkmcnt(0), in front of the branch.
+      asm volatile("" : "+v"(m), "+v"(l));
       if (g == 0) {
-        St[((wave * H + hp) * 16 + l15) * 2 + 0] = m;
-        St[((wave * H + hp) * 16 + l15) * 2 + 1] = 1.f / l;
+        const float il = 1.f / l;
+        *reinterpret_cast<f32x4*>(&St[((wave * H + hp) * 16 + l15) * 4]) = f32x4{m, m, il, il};
       }
+      THA_DBG_ONLY(dbg_st[hp][0] = m; dbg_st[hp][1] = 1.f / l;)
     }
   }
 
@@ -260,14 +386,17 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p, const ThaWeig
       stage(kb, true);
 #pragma unroll 1
       for (int t = 0; t < THA_KB / 16; ++t) {
-        f32x4 pr[H];
+        tfimm_f32x2 pr[H][2];
         logits(kb, t, pr);
 #pragma unroll
         for (int hp = 0; hp < H; ++hp) {
-          const float m = St[st_off + hp * 32 + 0];
-          const float il = St[st_off + hp * 32 + 1];
+          const tfimm_f32x2 m2 = *reinterpret_cast<const tfimm_f32x2*>(&St[st_off + hp * 64]);
+          const tfimm_f32x2 il2 = *reinterpret_cast<const tfimm_f32x2*>(&St[st_off + hp * 64 + 2]);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pr[hp][r] = __builtin_amdgcn_exp2f(pr[hp][r] - m) * il;
+          for (int u = 0; u < 2; ++u) {
+            const tfimm_f32x2 d = pr[hp][u] - m2;
+            pr[hp][u] = tfimm_f32x2{__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])} * il2;
+          }
         }
         // V^T fragments by transposing LDS reads: lane (l15, g) supplies the address of the 8-byte piece
         // (key 4g + l15/4, d 4*(l15%4)..+3) and receives keys 4g..4g+3 at d = l15 -- the MFMA "a" operand
@@ -275,12 +404,16 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p, const ThaWeig
 #pragma unroll
         for (int i = 0; i < HG; ++i) {
           const int hq = hq0 + i;
-          const float b = Wm[wm_off + 2 * H * H + H + hq];
-          f32x4 a = {b, b, b, b};
+          const tfimm_f32x2 b2 = Wm[wm_off + 2 * H * H + H + hq];
+          tfimm_f32x2 a_lo = b2, a_hi = b2;
 #pragma unroll
-          for (int hp = 0; hp < H; ++hp) a += Wm[wm_off + H * H + H + hp * H + hq] * pr[hp];
+          for (int hp = 0; hp < H; ++hp) {
+            const tfimm_f32x2 w2 = Wm[wm_off + H * H + H + hp * H + hq];
+            a_lo = __builtin_elementwise_fma(w2, pr[hp][0], a_lo);
+            a_hi = __builtin_elementwise_fma(w2, pr[hp][1], a_hi);
+          }
           // keys beyond the sequence carry the bias b, but their V rows are staged as zeros
-          const uint2 pu = make_uint2(pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]));
+          const uint2 pu = make_uint2(pack_bf2(a_lo[0], a_lo[1]), pack_bf2(a_hi[0], a_hi[1]));
           const bf16x4_t pf = __builtin_bit_cast(bf16x4_t, pu);
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
@@ -303,6 +436,63 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p, const ThaWeig
         }
     }
   }
+#ifdef TFIMM_THA_DBG
+  __syncthreads();
+  // mixing layers
+  if (p.wdev)
+    for (int id = tid; id < 2 * (H * H + H); id += 256) {
+      const float v = p.wdev[id];
+      const float e = (id >= H * H && id < H * H + H) ? v * LOG2E : v;
+      if (__float_as_uint(Wm[id][0]) != __float_as_uint(e) || __float_as_uint(Wm[id][1]) != __float_as_uint(e)) dbg_bad(6, &Wm[id]);
+    }
+  // zero pads of the K block, and the columns no fragment read touches (still poisoned)
+  for (int id = tid; id < THA_KB * H; id += 256) {
+    const int r = id / H, h = id - r * H;
+    for (int e = HD; e < HP; ++e)
+      if (Ks[r * p.kstr + h * HP + e] != 0) dbg_bad(7, &Ks[r * p.kstr + h * HP + e]);
+  }
+  for (int id = tid; id < THA_KB * (p.kstr - H * HP) / 2; id += 256) {
+    const int per = (p.kstr - H * HP) / 2, r = id / per, e = id - r * per;
+    const unsigned* q = reinterpret_cast<const unsigned*>(&Ks[r * p.kstr + H * HP]) + e;
+    if (*q != 0xDEADBEEFu) dbg_bad(9, q);
+  }
+  for (int id = tid; id < THA_KB * (p.vstr - D) / 2; id += 256) {
+    const int per = (p.vstr - D) / 2, r = id / per, e = id - r * per;
+    const unsigned* q = reinterpret_cast<const unsigned*>(&Vs[r * p.vstr + D]) + e;
+    if (*q != 0xDEADBEEFu) dbg_bad(9, q);
+  }
+  if (QLDS) {
+    for (int id = tid; id < 64 * (p.kstr - H * HP) / 2; id += 256) {
+      const int per = (p.kstr - H * HP) / 2, r = id / per, e = id - r * per;
+      const unsigned* q = reinterpret_cast<const unsigned*>(&Qs[r * p.kstr + H * HP]) + e;
+      if (*q != 0xDEADBEEFu) dbg_bad(9, q);
+    }
+    for (int rr = srow; rr < 64; rr += 32) {
+      const int t = qc * 64 + rr;
+      for (int c = sc0; c < CH; c += 8) {
+        uint4 u = make_uint4(0u, 0u, 0u, 0u);
+        if (t < p.n) u = *reinterpret_cast<const uint4*>(p.qkv + (row0 + t) * p.ld + c * 8);
+        const int h = c / CPH;
+        const uint4* qq = reinterpret_cast<const uint4*>(&Qs[rr * p.kstr + h * HP + (c - h * CPH) * 8]);
+        const uint4 a = *qq;
+        if (a.x != u.x || a.y != u.y || a.z != u.z || a.w != u.w) dbg_bad(8, qq);
+      }
+      for (int h = sc0; h < H; h += 8)
+        for (int e = HD; e < HP; ++e)
+          if (Qs[rr * p.kstr + h * HP + e] != 0) dbg_bad(8, &Qs[rr * p.kstr + h * HP + e]);
+    }
+  }
+  if (g == 0) {
+    for (int hp = 0; hp < H; ++hp) {
+      const float* sp = &St[((wave * H + hp) * 16 + l15) * 4];
+      if (__float_as_uint(sp[0]) != __float_as_uint(dbg_st[hp][0]) || __float_as_uint(sp[2]) != __float_as_uint(dbg_st[hp][1]))
+        dbg_bad(10, sp);
+    }
+  }
+  if (blockIdx.x < 1024)
+    for (int i = tid; i < 4 * H * 16 * 2; i += 256) tha_dbg_st[blockIdx.x * 512 + i] = St[(i >> 1) * 4 + (i & 1) * 2];
+  if (tid == 0) dbg[13] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 template <int H, int HG, int DT, bool QLDS>
@@ -463,6 +653,20 @@ __global__ void copy_rows_kernel(const uint4* __restrict__ src, uint4* __restric
 
 }  // namespace
 
+#ifdef TFIMM_THA_DBG
+extern "C" __attribute__((visibility("default"))) int tfimm_hip_dbg_tha_read(void* host_dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(tha_dbg_buf), bytes, 0, hipMemcpyDeviceToHost);
+}
+extern "C" __attribute__((visibility("default"))) int tfimm_hip_dbg_tha_read3(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(tha_dbg_run), bytes, 0, hipMemcpyDeviceToHost);
+}
+extern "C" __attribute__((visibility("default"))) int tfimm_hip_dbg_tha_read2(void* st_dst, size_t st_bytes, void* ck_dst, size_t ck_bytes) {
+  int rc = (int)hipMemcpyFromSymbol(st_dst, HIP_SYMBOL(tha_dbg_st), st_bytes, 0, hipMemcpyDeviceToHost);
+  if (rc) return rc;
+  return (int)hipMemcpyFromSymbol(ck_dst, HIP_SYMBOL(tha_dbg_ck), ck_bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 extern "C" int tfimm_hip_talking_heads_attention(const tfimm_tha_desc* dp, void* stream) {
   if (!dp) TFIMM_FAIL(TFIMM_EINVAL, "talking_heads_attention: null descriptor");
   const tfimm_tha_desc& d = *dp;
@@ -501,17 +705,11 @@ extern "C" int tfimm_hip_talking_heads_attention(const tfimm_tha_desc* dp, void*
   const int hp_ = (d.hd + 31) / 32 * 32;
   a.kstr = ((d.heads * hp_ + 8 - 72 + 127) / 128) * 128 + 72;
   a.vstr = ((a.dmodel + 8 - 72 + 127) / 128) * 128 + 72;
-  const size_t base = (size_t)THA_KB * a.kstr * 2 + (size_t)THA_KB * a.vstr * 2 + (size_t)4 * d.heads * 16 * 2 * 4 +
-                      (size_t)((2 * (d.heads * d.heads + d.heads) + 3) / 4 * 4) * 4;
+  const size_t base = (size_t)THA_KB * a.kstr * 2 + (size_t)THA_KB * a.vstr * 2 + (size_t)4 * d.heads * 16 * 4 * 4 +   // St: pairs
+                      (size_t)2 * (d.heads * d.heads + d.heads) * 8;                                                      // Wm: pairs
   const size_t qbytes = (size_t)64 * a.kstr * 2;
   a.q_in_lds = (base + qbytes <= 160 * 1024) ? 1 : 0;   // else Q fragments are re-read from L1/L2 per key tile
   size_t lds = base + (a.q_in_lds ? qbytes : 0);
-  {
-    // experiment switch (profiles/NOTES_r03.md section 9): ask for more LDS than the kernel needs so that no other workgroup
-    // shares its CU -- TFIMM_THA_LDS_KIB=160: nothing with an LDS allocation fits next to it
-    static const int want = getenv("TFIMM_THA_LDS_KIB") ? atoi(getenv("TFIMM_THA_LDS_KIB")) : 0;
-    if (want > 0 && (size_t)want * 1024 > lds && want <= 160) lds = (size_t)want * 1024;
-  }
   if (lds > 160 * 1024) TFIMM_FAIL(TFIMM_EUNSUP, "talking_heads_attention: embed dim %d needs %zu bytes of LDS", a.dmodel, lds);
   return d.hd == 32 ? launch_tha_heads<2>(a, w, lds, st) : launch_tha_heads<3>(a, w, lds, st);
 }

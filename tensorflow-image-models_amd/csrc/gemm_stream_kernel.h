@@ -154,9 +154,13 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
       const int m = m0 + r;
       const bool ok = valid && m < p.M;
       if (KMODE == K_DENSE) {
-        // TFIMM_GEMM_DBG & 128 (measurement only): every tile fetches the FIRST activation panel -- what the loop does when
+        // probe build (-DTFIMM_STREAM_DBG), TFIMM_GEMM_DBG & 128: every tile fetches the FIRST activation panel -- what the loop does when
         // the A operand always hits in L2
+#ifdef TFIMM_STREAM_DBG
         const int msrc = (pa.dbg & 128) ? r : m;
+#else
+        const int msrc = m;
+#endif
         a_off[j] = ok ? (unsigned)(((size_t)msrc * p.lda + a_chunk(j) * 8) * 2) : kOobOffset;
         a_iy0[j] = a_ix0[j] = a_pix[j] = 0;
       } else {
@@ -176,7 +180,11 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
       const int r = (wave * B_INSTR + j) * 8 + lrow;
       const int chunk = lpc ^ ((r >> 1) & 7);
       const int n = n0 + r;
+#ifdef TFIMM_STREAM_DBG
       const int nsrc = (pa.dbg & 256) ? r : n;      // measurement only: every tile fetches the first weight panel
+#else
+      const int nsrc = n;
+#endif
       b_off[j] = (valid && n < p.N) ? (unsigned)(((size_t)nsrc * p.ldw + chunk * 8) * 2) : kOobOffset;
     }
     s_ky = s_kx = s_ci0 = 0;
@@ -364,6 +372,9 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
       const int d = i * 32 + it * RPI;
       unsigned off = res_off0 + (unsigned)d * ldr2;
       off -= (rm0 + d >= resmod_eff) ? res_wrap : 0u;
+#ifdef TFIMM_STREAM_DBG   // probe build: TFIMM_GEMM_DBG & 2 = every residual load out of range (returns zeros, no memory access)
+      if (pa.dbg & 2) off = kOobOffset;
+#endif
       rres[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, (int)off, 0, 0));
     };
 
@@ -394,7 +405,11 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
       // This wave's DMA pieces of the current step must have landed.  VMEM operations retire in
       // issue order, and the only ones younger than that DMA are the previous tile's epilogue
       // (>= TM*ITS store instructions for an interior tile): leave exactly those in flight.
+#ifdef TFIMM_STREAM_DBG   // probe build: TFIMM_GEMM_DBG & 1 = no counted wait (every step drains all VMEM)
+      if (VEC && stores_pending && !(pa.dbg & 1)) {
+#else
       if (VEC && stores_pending) {
+#endif
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TM * ITS) : "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -716,6 +731,12 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   }
   // the last step's (all out-of-range) prefetch must have landed before this workgroup's LDS is released
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef TFIMM_STREAM_DBG   // probe build: TFIMM_GEMM_DBG & 4 = all waves leave together, after everything of every wave has landed
+  if (pa.dbg & 4) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+#endif
 }
 
 struct StreamTileCfg {

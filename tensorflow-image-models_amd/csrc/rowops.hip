@@ -698,12 +698,15 @@ __global__ void __launch_bounds__(256) dwconv_strip_kernel(const bf16_t* __restr
     const int t = item / cgs;
     const int sxi = t % sx, oy = t / sx;
     const int ox0 = sxi * PX, c0 = cg * CV;
-    float acc[PX][CV];
+    // channel PAIRS throughout (accumulators, taps and pixels are tfimm_f32x2 of channels 2i, 2i+1): written with scalars, the
+    // SLP vectoriser paired registers of different origin and bridged them with operand selects (v_pk_fma_f32 ... op_sel:[0,1,0]),
+    // which gfx950 gets wrong next to MFMA waves of another kernel (tools/isa_lint.py; profiles/NOTES_r04.md section 1)
+    tfimm_f32x2 acc[PX][CV / 2];
 #pragma unroll
-    for (int e = 0; e < CV; ++e) {
-      const float be = bias ? bias[c0 + e] : 0.f;
+    for (int i = 0; i < CV / 2; ++i) {
+      const tfimm_f32x2 be = bias ? *reinterpret_cast<const tfimm_f32x2*>(bias + c0 + 2 * i) : tfimm_f32x2{0.f, 0.f};
 #pragma unroll
-      for (int px = 0; px < PX; ++px) acc[px][e] = be;
+      for (int px = 0; px < PX; ++px) acc[px][i] = be;
     }
     const int ixb = ox0 * S - pad_l;
     const bf16_t* ximg = x + (size_t)b * H * W * C + c0;
@@ -712,14 +715,15 @@ __global__ void __launch_bounds__(256) dwconv_strip_kernel(const bf16_t* __restr
       const int iy = oy * S - pad_t + ky;
       const bool rok = (unsigned)iy < (unsigned)H;
       const int iyc = rok ? iy : 0;
-      float wr[K][CV];
+      tfimm_f32x2 wr[K][CV / 2];
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
         const float* wp = w + (size_t)(ky * K + kx) * C + c0;
 #pragma unroll
         for (int q = 0; q < CV / 4; ++q) {
           const float4 w4 = *reinterpret_cast<const float4*>(wp + 4 * q);
-          wr[kx][4 * q + 0] = w4.x; wr[kx][4 * q + 1] = w4.y; wr[kx][4 * q + 2] = w4.z; wr[kx][4 * q + 3] = w4.w;
+          wr[kx][2 * q] = tfimm_f32x2{w4.x, w4.y};
+          wr[kx][2 * q + 1] = tfimm_f32x2{w4.z, w4.w};
         }
       }
       const bf16_t* xrow = ximg + (size_t)iyc * W * C;
@@ -734,16 +738,18 @@ __global__ void __launch_bounds__(256) dwconv_strip_kernel(const bf16_t* __restr
       for (int col = 0; col < COLS; ++col) {
         const int ix = ixb + col;
         const float m = (rok && (unsigned)ix < (unsigned)W) ? 1.f : 0.f;
-        float v[CV];
-        dw_unpack<CV>(raw[col], v);
+        const tfimm_f32x2 m2 = {m, m};
+        float vs[CV];
+        dw_unpack<CV>(raw[col], vs);
+        tfimm_f32x2 v[CV / 2];
 #pragma unroll
-        for (int e = 0; e < CV; ++e) v[e] *= m;
+        for (int i = 0; i < CV / 2; ++i) v[i] = tfimm_f32x2{vs[2 * i], vs[2 * i + 1]} * m2;
 #pragma unroll
         for (int px = 0; px < PX; ++px) {
           const int kx = col - px * S;   // compile-time after unrolling
           if (kx >= 0 && kx < K) {
 #pragma unroll
-            for (int e = 0; e < CV; ++e) acc[px][e] = fmaf(v[e], wr[kx][e], acc[px][e]);
+            for (int i = 0; i < CV / 2; ++i) acc[px][i] = __builtin_elementwise_fma(v[i], wr[kx][i], acc[px][i]);
           }
         }
       }
@@ -754,11 +760,9 @@ __global__ void __launch_bounds__(256) dwconv_strip_kernel(const bf16_t* __restr
     bf16_t* yrow = y + ((size_t)((size_t)b * OH + oy) * OW) * C + c0;
 #pragma unroll
     for (int px = 0; px < PX; ++px) {
-#pragma unroll
-      for (int e = 0; e < CV; ++e) acc[px][e] = act1(acc[px][e], actp);
       uint32_t pk[CV / 2];
 #pragma unroll
-      for (int i = 0; i < CV / 2; ++i) pk[i] = pack_bf2(acc[px][2 * i], acc[px][2 * i + 1]);
+      for (int i = 0; i < CV / 2; ++i) pk[i] = pack_bf2(act1(acc[px][i][0], actp), act1(acc[px][i][1], actp));
       const bool ok = ox0 + px < OW;
       if (ok) {
         vec_t u;

@@ -216,11 +216,14 @@ class Program:
         return sorted(t for t in written if t in needed or t in keep)
 
     def supports_branches(self) -> bool:
-        """False for programs with the talking-heads attention launch (CaiT).  tools/branch_hunt.py: next to launches of a
-        second stream the H = 4 instance of that kernel (cait_xxs24 / xxs36) is not bit-reproducible -- alone it is, with any
-        number of workgroups per CU (tools/tha_repro_probe.py), and so is every other configuration tried under parallel
-        branches (profiles/NOTES_r03.md section 9: open).  Until that is understood such programs keep one branch."""
-        return not any(op.kind == "talking_heads_attention" for op in self.ops)
+        """Every program may run as parallel branches.  (Round 3 excluded the talking-heads programs -- CaiT: the H = 4 launch
+        was not bit-reproducible next to GEMM launches of another stream.  Cause, found in round 4: hipcc had emitted packed fp32
+        FMAs that take the HIGH half of a source pair into the LOW result (``op_sel:[0,1,0]``), which gfx950 evaluates
+        wrongly in lanes 48..63 while waves of the persistent GEMM kernel share the SIMD; the kernel no longer contains such
+        instructions, ``tools/isa_lint.py`` keeps them out of every product kernel, and
+        ``tests/test_gpu_branches.py::test_talking_heads_next_to_the_gemm_that_disturbed_it`` launches the pair 60 times.
+        profiles/NOTES_r04.md section 1.)"""
+        return True
 
     def make_branches(self, batch: int, parts: int = 2, device: str = "cuda") -> List["Plan"]:
         """``parts`` plans over consecutive slices of one batch (sizes as even as possible, each with its own activation

@@ -49,19 +49,74 @@ def test_small_batches_keep_one_branch():
 
 
 @pytest.mark.gpu
-def test_talking_heads_programs_keep_one_branch():
-    """CaiT: the talking-heads launch is not bit-reproducible next to launches of another stream (Program.supports_branches,
-    profiles/NOTES_r03.md section 9) -- such programs ignore ``branches`` and stay reproducible."""
+def test_talking_heads_programs_run_as_branches_bit_for_bit():
+    """CaiT under parallel branches (excluded in round 3: profiles/NOTES_r04.md section 1 has the cause and the fix): every
+    replay of the forked recording gives the single-plan bits."""
     import model_checks as mc
     model = tfimm.create_model("cait_xxs24_224")
     model.set_weights(synthetic_weights(model, 2021))
-    assert not model.program().supports_branches()
-    x = mc.make_input(model.cfg, 8)
+    assert model.program().supports_branches()
+    x = mc.make_input(model.cfg, 64)
     want = model(x).numpy()
     model.branches = 2
-    runs = [model(x).numpy() for _ in range(3)]
+    runs = [model(x).numpy() for _ in range(8)]
+    assert [k for k in model._plans if "branches" in k]
     assert all(np.array_equal(r, want) for r in runs)
-    assert not [k for k in model._plans if "branches" in k]
+
+
+@pytest.mark.gpu
+def test_talking_heads_next_to_the_gemm_that_disturbed_it():
+    """The pair of launches that was not reproducible in round 3, 60 times on two streams: talking-heads attention (heads 4,
+    hd 48, 196 tokens) while 768 -> 192 GEMMs with residual on the 256 x 64 tiles (four and eight waves) run back to back on
+    another stream.  Every talking-heads result must equal the solo run bit for bit, and so must the GEMM's."""
+    import math
+
+    import torch
+
+    import hip_ops as H
+    from tfimm.engine import pack
+    B, N, heads, hd = 64, 196, 4, 48
+    r = np.random.default_rng(1)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    qkv = torch.randn(B * N, 3 * heads * hd, device="cuda", generator=g).to(torch.bfloat16)
+    wl = (r.standard_normal((heads, heads)) / heads ** 0.5 + np.eye(heads)).astype(np.float32)
+    ww = (r.standard_normal((heads, heads)) / heads ** 0.5 + np.eye(heads)).astype(np.float32)
+    bl = (0.3 * r.standard_normal(heads)).astype(np.float32)
+    bw = (0.02 * r.standard_normal(heads)).astype(np.float32)
+
+    def tha():
+        return H.talking_heads_attention(qkv, B, N, heads, hd, hd ** -0.5, wl, bl, ww, bw)
+
+    ref = tha().view(torch.int16).clone()
+    torch.cuda.synchronize()
+    M, K, Nn = 12544, 768, 192
+    a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    wt, _ = pack.pack_dense((r.standard_normal((K, Nn)) / math.sqrt(K)).astype(np.float32), None)
+    wd, bias = H.dev_bits(wt), H.dev_f32(r.standard_normal(Nn).astype(np.float32))
+    res = torch.randn(M, Nn, device="cuda", generator=g).to(torch.bfloat16)
+    outs = {hint: torch.empty(M, Nn, dtype=torch.bfloat16, device="cuda") for hint in (27, 24)}
+
+    def gemm(hint):
+        return H.gemm(a, wd, Nn, K, bias=bias, residual=res, tile_hint=hint, out=outs[hint])
+
+    gref = {}
+    for hint in outs:
+        gemm(hint)
+        torch.cuda.synchronize()
+        gref[hint] = outs[hint].view(torch.int16).clone()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    bad = gbad = 0
+    for rep in range(60):
+        hint = (27, 24)[rep & 1]
+        with torch.cuda.stream(sb):
+            for _ in range(6):
+                gemm(hint)
+        with torch.cuda.stream(sa):
+            o = tha()
+        torch.cuda.synchronize()
+        bad += int(not torch.equal(o.view(torch.int16), ref))
+        gbad += int(not torch.equal(outs[hint].view(torch.int16), gref[hint]))
+    assert bad == 0 and gbad == 0, f"talking-heads results differing from the solo run: {bad} / 60; GEMM results: {gbad} / 60"
 
 
 @pytest.mark.gpu

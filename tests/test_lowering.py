@@ -329,4 +329,4 @@ def test_live_tensors_across_a_cut_and_branch_support():
     assert sorted(prog.tensors[t].C for t in prog.live_across(j)) == [64, 256]
     assert prog.supports_branches()
     _, cait = _kinds("cait_test_model")
-    assert not cait.supports_branches()
+    assert cait.supports_branches()          # round 4: the talking-heads kernel is reproducible next to other launches

@@ -1,0 +1,52 @@
+#!/bin/bash
+# Round-4 GPU sessions, one parameterised script (replaces the per-session gpu_r3*.sh files):  tools/gpu_r4.sh STAGE...
+#   hunt    co-residency probes (tools/tha_coresident_probe.py) on the product library and the two probe builds
+#   rccl    bench.py --gpus 1 --spawn --backend nccl (world = 1 through RCCL) + the multirank tests
+#   bench   the default bench line (ResNet-50 + the `also` workloads)
+#   tests   pytest -m gpu
+#   cait    CaiT under parallel branches: TFIMM_BRANCHES=2 tests + flaky/branch hunts
+#   tests2  pytest -m gpu with every model test on two parallel branches (TFIMM_BRANCHES=2)
+#   memset  the round-3 memset-node observation again (TFIMM_MEMSET_NODE=1 flaky hunt on EfficientNet-B4)
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r4; mkdir -p $O; cd $R
+export TMPDIR=/tmp
+P=$R/tools/probes/bin
+for stage in "$@"; do
+  case $stage in
+    hunt)
+      timeout 600 python tools/tha_coresident_probe.py 10 gemm,syn > $O/hunt_tree.txt 2>&1
+      TFIMM_HIP_LIB=$P/libtfimm_hip_thadbg.so timeout 600 python tools/tha_coresident_probe.py 10 gemm,syn > $O/hunt_thadbg.txt 2>&1
+      [ -f $P/libtfimm_hip_before_fix.so ] && TFIMM_HIP_LIB=$P/libtfimm_hip_before_fix.so timeout 600 python tools/tha_coresident_probe.py 10 gemm > $O/hunt_before_fix.txt 2>&1
+      timeout 600 python tools/tha_coresident_probe.py 5 gemm,syn,ldsret > $O/hunt_ldsret.txt 2>&1
+      for bits in ${HUNT_BITS:-}; do
+        TFIMM_GEMM_DBG=$bits TFIMM_HIP_LIB=$P/libtfimm_hip_streamdbg.so timeout 600 python tools/tha_coresident_probe.py 10 gemm > $O/hunt_streamdbg_$bits.txt 2>&1
+      done
+      tail -n 40 $O/hunt_tree.txt $O/hunt_thadbg.txt $O/hunt_before_fix.txt $O/hunt_ldsret.txt; tail -n 6 $O/hunt_streamdbg_*.txt ;;
+    rccl)
+      timeout 900 python bench.py --gpus 1 --spawn --backend nccl --steps 5 --warmup 2 --no-cpu-baseline --extra "" > $O/bench_rccl_world1.json 2> $O/bench_rccl_world1.err
+      echo "rccl rc=$?"; tail -c 600 $O/bench_rccl_world1.json
+      timeout 1200 python -m pytest tests/test_gpu_multirank.py -x -q > $O/multirank.txt 2>&1; tail -n 3 $O/multirank.txt ;;
+    bench)
+      timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+      python - <<PY
+import json
+d = json.loads(open("$O/bench.json").read().strip().splitlines()[-1])
+print("headline", d["headline"], "ms", d["ms_per_step"], "median", d.get("median_ms_per_step"), "single", d["config"]["single_branch_ms_per_step"],
+      "frac", d["roofline"]["frac"], d["roofline"].get("frac_timed_mode"))
+for k, v in d["also"].items():
+    print(k, v.get("value"), v.get("ms_per_step"), v.get("single_branch_ms_per_step"), (v.get("roofline") or {}).get("frac"))
+PY
+      ;;
+    tests)
+      timeout 3000 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; echo "tests rc=$?"; tail -n 5 $O/pytest_gpu.txt ;;
+    cait)
+      TFIMM_BRANCHES=2 timeout 1500 python -m pytest tests/test_gpu_models.py tests/test_gpu_branches.py -m gpu -q -k "cait" > $O/cait_branches.txt 2>&1; tail -n 4 $O/cait_branches.txt
+      timeout 600 python tools/branch_hunt.py cait_xxs24_224 64 12 > $O/branch_hunt.txt 2>&1; tail -n 6 $O/branch_hunt.txt
+      timeout 600 python tools/flaky_hunt.py cait_xxs24_224 64 12 3 > $O/flaky_cait.txt 2>&1; tail -n 4 $O/flaky_cait.txt ;;
+    tests2)
+      TFIMM_BRANCHES=2 timeout 3000 python -m pytest tests -m gpu -q > $O/pytest_gpu_branches2.txt 2>&1; echo "tests(branches=2) rc=$?"; tail -n 8 $O/pytest_gpu_branches2.txt ;;
+    memset)
+      TFIMM_MEMSET_NODE=1 timeout 900 python tools/flaky_hunt.py efficientnet_b4 256 12 3 > $O/flaky_b4_memset_node.txt 2>&1; tail -n 6 $O/flaky_b4_memset_node.txt ;;
+    *) echo "unknown stage $stage" ;;
+  esac
+done
