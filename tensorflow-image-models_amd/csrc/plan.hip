@@ -76,22 +76,27 @@ template <typename R, typename... P> constexpr size_t arity(R (*)(P...)) { retur
 #define TFIMM_ADAPTER(NAME, ...)                                                                          \
   {#NAME, {[](const Arg* a, void* s) -> int {                                                             \
              return invoke_impl<__VA_ARGS__>(NAME, a, s, std::make_index_sequence<arity(NAME)>{});       \
-           }, arity(NAME)}}
+           }, arity(NAME), 0}}
+// entry points that take ONE descriptor: its size is recorded so that a blob's struct can be checked against it
+#define TFIMM_ADAPTER_DESC(NAME, DESC)                                                                    \
+  {#NAME, {[](const Arg* a, void* s) -> int {                                                             \
+             return invoke_impl<const DESC*>(NAME, a, s, std::make_index_sequence<arity(NAME)>{});       \
+           }, arity(NAME), sizeof(DESC)}}
 
-struct Entry { adapter_fn fn; size_t nargs; };
+struct Entry { adapter_fn fn; size_t nargs; size_t desc_bytes; };
 
 const std::map<std::string, Entry>& table() {
   using vp = const void*;
   using mp = void*;
   using fp = const float*;
   static const std::map<std::string, Entry> t = {
-      TFIMM_ADAPTER(tfimm_hip_gemm, const tfimm_gemm_desc*),
-      TFIMM_ADAPTER(tfimm_hip_conv_chain, const tfimm_chain_desc*),
-      TFIMM_ADAPTER(tfimm_hip_mlp_fused, const tfimm_mlp_desc*),
-      TFIMM_ADAPTER(tfimm_hip_expand_dwconv, const tfimm_expand_dw_desc*),
-      TFIMM_ADAPTER(tfimm_hip_stem_conv_pool, const tfimm_stem_desc*),
-      TFIMM_ADAPTER(tfimm_hip_attention, const tfimm_attn_desc*),
-      TFIMM_ADAPTER(tfimm_hip_talking_heads_attention, const tfimm_tha_desc*),
+      TFIMM_ADAPTER_DESC(tfimm_hip_gemm, tfimm_gemm_desc),
+      TFIMM_ADAPTER_DESC(tfimm_hip_conv_chain, tfimm_chain_desc),
+      TFIMM_ADAPTER_DESC(tfimm_hip_mlp_fused, tfimm_mlp_desc),
+      TFIMM_ADAPTER_DESC(tfimm_hip_expand_dwconv, tfimm_expand_dw_desc),
+      TFIMM_ADAPTER_DESC(tfimm_hip_stem_conv_pool, tfimm_stem_desc),
+      TFIMM_ADAPTER_DESC(tfimm_hip_attention, tfimm_attn_desc),
+      TFIMM_ADAPTER_DESC(tfimm_hip_talking_heads_attention, tfimm_tha_desc),
       TFIMM_ADAPTER(tfimm_hip_cast_input, vp, int, mp, int64_t, int, int),
       TFIMM_ADAPTER(tfimm_hip_cast_input_pad, vp, int, mp, int, int, int, int, int, int, int, int),
       TFIMM_ADAPTER(tfimm_hip_row_stats, vp, float*, int64_t, int, int64_t, float),
@@ -151,24 +156,25 @@ int parse(const void* blob, size_t bytes, Plan& pl) {
     pl.const_src.push_back(r.get<uint64_t>());
     pl.const_off.push_back(off);
     off += align256(pl.const_bytes.back());
-    if (pl.const_src.back() + pl.const_bytes.back() > bytes) TFIMM_FAIL(TFIMM_EINVAL, "plan: constant outside the blob");
+    if (pl.const_bytes.back() > bytes || pl.const_src.back() > bytes - pl.const_bytes.back())      // (overflow-safe)
+      TFIMM_FAIL(TFIMM_EINVAL, "plan: constant outside the blob");
   }
   pl.workspace_bytes = off;
   for (uint32_t i = 0, n = r.get<uint32_t>(); i < n && r.ok; ++i) {
     const uint64_t nb = r.get<uint64_t>(), src = r.get<uint64_t>();
-    if (src + nb > bytes) TFIMM_FAIL(TFIMM_EINVAL, "plan: host constant outside the blob");
+    if (nb > bytes || src > bytes - nb) TFIMM_FAIL(TFIMM_EINVAL, "plan: host constant outside the blob");
     pl.host_consts.emplace_back(static_cast<const uint8_t*>(blob) + src, static_cast<const uint8_t*>(blob) + src + nb);
   }
   for (uint32_t i = 0, n = r.get<uint32_t>(); i < n && r.ok; ++i) {
     StructSpec s;
     const uint32_t nb = r.get<uint32_t>(), nr = r.get<uint32_t>();
-    if (!r.ok || r.p + nb > r.end) TFIMM_FAIL(TFIMM_EINVAL, "plan: truncated struct");
+    if (!r.ok || nb > (size_t)(r.end - r.p)) TFIMM_FAIL(TFIMM_EINVAL, "plan: truncated struct");
     s.bytes.assign(r.p, r.p + nb);
     r.p += nb;
-    for (uint32_t k = 0; k < nr; ++k) {
+    for (uint32_t k = 0; k < nr && r.ok; ++k) {
       Reloc rl;
       rl.field_offset = r.get<uint32_t>(); rl.kind = r.get<uint32_t>(); rl.aux = r.get<uint32_t>(); rl.value = r.get<uint64_t>();
-      if (rl.field_offset + sizeof(void*) > nb) TFIMM_FAIL(TFIMM_EINVAL, "plan: relocation outside its struct");
+      if (nb < sizeof(void*) || rl.field_offset > nb - sizeof(void*)) TFIMM_FAIL(TFIMM_EINVAL, "plan: relocation outside its struct");
       s.relocs.push_back(rl);
     }
     pl.structs.push_back(std::move(s));
@@ -177,7 +183,7 @@ int parse(const void* blob, size_t bytes, Plan& pl) {
     Call c;
     c.name = r.str();
     const uint32_t na = r.get<uint32_t>();
-    for (uint32_t k = 0; k < na; ++k) {
+    for (uint32_t k = 0; k < na && r.ok; ++k) {
       ArgSpec a;
       a.kind = r.get<uint32_t>(); a.aux = r.get<uint32_t>(); a.value = r.get<uint64_t>();
       c.spec.push_back(a);
@@ -206,6 +212,27 @@ int parse(const void* blob, size_t bytes, Plan& pl) {
   }
   if (!r.ok) TFIMM_FAIL(TFIMM_EINVAL, "plan: truncated blob");
   if (pl.input_call < 0 || pl.input_call >= (int)pl.calls.size()) TFIMM_FAIL(TFIMM_EINVAL, "plan: no input call");
+  // everything plan_forward / plan_output index with: checked here, once
+  if (pl.calls[pl.input_call].spec.size() < 2) TFIMM_FAIL(TFIMM_EINVAL, "plan: the input call takes (pointer, dtype, ...)");
+  if (pl.stem_call >= 0) {
+    if (pl.stem_call >= (int)pl.calls.size() || pl.stem_struct < 0 || pl.stem_struct >= (int)pl.structs.size() ||
+        pl.structs[pl.stem_struct].bytes.size() < sizeof(tfimm_stem_desc))
+      TFIMM_FAIL(TFIMM_EINVAL, "plan: bad stem reference");
+  }
+  for (const auto& o : pl.outputs)
+    if (o.slab >= pl.slab_off.size() || o.offset > pl.slab_bytes[o.slab]) TFIMM_FAIL(TFIMM_EINVAL, "plan: output '%s' outside its slab", o.name.c_str());
+  // a descriptor argument must be at least as large as the struct its entry point reads
+  for (const auto& c : pl.calls) {
+    if (c.is_memset) continue;
+    const auto& e = table().find(c.name)->second;
+    for (size_t k = 0; k < c.spec.size(); ++k)
+      if (c.spec[k].kind == A_STRUCT) {
+        if (c.spec[k].aux >= pl.structs.size()) TFIMM_FAIL(TFIMM_EINVAL, "plan: bad struct reference");
+        if (e.desc_bytes && pl.structs[c.spec[k].aux].bytes.size() < e.desc_bytes)
+          TFIMM_FAIL(TFIMM_EINVAL, "plan: %s descriptor has %zu bytes, the entry point reads %zu", c.name.c_str(),
+                     pl.structs[c.spec[k].aux].bytes.size(), e.desc_bytes);
+      }
+  }
   return 0;
 }
 

@@ -28,13 +28,41 @@ def _bf(a):
     return pack.bf16_bits_to_f32(pack.to_bf16_bits(np.asarray(a, dtype=np.float32))).reshape(np.shape(a))
 
 
+_TIGHT = False     # set by the tight_* cases at the bottom of this file: _err then measures element-wise, in bf16 ulps
+
+
 def _err(got, ref):
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, (got.shape, ref.shape)
     if not np.all(np.isfinite(got)):
         return float("inf")
+    if _TIGHT:
+        return _err_ulp(got, ref)
     return float(np.max(np.abs(got - ref)) / (np.max(np.abs(ref)) + 1e-6))
+
+
+def _err_ulp(got, ref):
+    """Element-wise bar of the tight cases: every stored bf16 value within 2 bf16 ulps OF ITS OWN REFERENCE VALUE (ulp =
+    2^(floor(log2 |ref|) - 7)), plus a floor of 2^-14 of the tensor's rms for values so small that fp32 accumulation noise
+    and the 1.6e-5 of the GELU polynomial exceed their ulp.  Returned: max |got - ref| / allowed (<= 1 passes; a launch with a
+    single rounding measures 0.25 = half an ulp here).  A wrong
+    epsilon, a tanh-form GELU (up to 5e-4 off where the exact value is ~0.02) or an activation on the wrong side of the
+    residual add are all several units on this scale; rel-to-max 1e-2 sees none of them."""
+    a = np.abs(ref)
+    ulp = np.exp2(np.floor(np.log2(np.maximum(a, 1e-30))) - 7)
+    rms = np.sqrt(np.mean(ref * ref))
+    err = np.abs(got - ref)
+    strict = float(np.max(err / (2.0 * ulp + rms * 2.0 ** -14)))
+    if _TIGHT == 1 or strict <= 1.0:
+        return strict
+    # _TIGHT == 2, launches with a bf16 intermediate (conv_chain, mlp_fused, expand_dwconv): an intermediate value within fp32
+    # accumulation noise of a rounding boundary may round the other way than in the reference (~5e-4 of them), which moves the
+    # outputs it feeds by |w| ulp(intermediate) -- many ulps of an output that happens to be near zero.  Those are isolated
+    # elements: at most 0.5 % of the tensor may exceed the strict bar, and none may exceed 2 ulps + 2^-8 rms.
+    over = float(np.mean(err > 2.0 * ulp + rms * 2.0 ** -14))
+    loose = float(np.max(err / (2.0 * ulp + rms * 2.0 ** -8)))
+    return max(over / 0.005, loose)
 
 
 def _cpu(t):
@@ -848,6 +876,12 @@ def _ln_gemm_case(M, K, N, act, seed, tile=0, offset=0.0, bias=True):
     bf = (bet.astype(np.float64) @ w.astype(np.float64) + b).astype(np.float32)
     wt, bvec = pack.pack_dense(wf, bf)
     c1 = pack.pack_ln_c1(wt, N, K)
+    if _TIGHT:
+        # the arithmetic of the launch itself: exact statistics, the bf16-rounded folded weights it multiplies with, fp64
+        # accumulation, ONE rounding (of the stored output)
+        wr = pack.bf16_bits_to_f32(wt).astype(np.float64)[:N, :K]                # [N][K], gamma folded
+        xh = (x64 - x64.mean(1, keepdims=True)) / np.sqrt(x64.var(1, keepdims=True) + eps)
+        y = O.activation(torch.from_numpy(xh @ wr.T + bvec.astype(np.float64)), act).numpy()
     xd = Hh.dev_bf16(x)
     st = Hh.row_stats(xd, eps)
     got = Hh.gemm(xd, Hh.dev_bits(wt), N, K, bias=Hh.dev_f32(bvec), act=act, tile_hint=tile, ln_stats=st, ln_c1=Hh.dev_bits(c1))
@@ -1248,7 +1282,10 @@ def _mlp_fused_case(M, seed, act="gelu", residual_is_x=True, layer_scale=False, 
     mean = xd.mean(axis=1, keepdims=True)
     var = ((xd - mean) ** 2).mean(axis=1, keepdims=True)
     w1r = pack.bf16_bits_to_f32(w1).astype(np.float64)                     # [Hd][C], gamma folded
-    hpre = ((xd - mean) / np.sqrt(var + eps)) @ w1r.T + b1f.astype(np.float64)
+    xhat = (xd - mean) / np.sqrt(var + eps)
+    if _TIGHT:
+        xhat = _bf(xhat.astype(np.float32)).astype(np.float64)            # the launch rounds the normalised rows to bf16 (the MFMA operand)
+    hpre = xhat @ w1r.T + b1f.astype(np.float64)
     hact = _bf(O.activation(torch.from_numpy(hpre), act).numpy().astype(np.float32)).astype(np.float64)
     order = pack.chain_k_order(Hd)
     w2r = np.zeros((Cc, Hd))
@@ -1293,6 +1330,50 @@ CASES["grouped3x3_c256_g32_s2_odd"] = lambda: _grouped_case(2, 29, 23, 256, 32, 
 CASES["grouped3x3_c1024_g32_7x7"] = lambda: _grouped_case(3, 7, 7, 1024, 32, 1, 192)              # 32 per group: dense 32 x 32 blocks
 CASES["grouped3x3_c64_g4_tiny"] = lambda: _grouped_case(1, 3, 5, 64, 4, 1, 193, act="")           # 16 per group, partial pixel tile
 CASES["grouped3x3_c96_g6_many_tiles"] = lambda: _grouped_case(9, 40, 40, 96, 6, 1, 194)           # 3 super-groups: last workgroup half empty
+
+
+# ---------------------------------------------------------------------------------------------
+# Tight cases: the fused product kernels at the layer shapes (and tiles) of the scored workloads, element-wise in bf16 ulps.
+# Every reference above already rounds where the launch rounds (bf16 operands, the folded weights the launch multiplies with,
+# one bf16 rounding at each tensor the unfused path would store); under _TIGHT the metric is _err_ulp and the bar is 1
+# (= 2 ulps of the element + 2^-14 of the tensor's rms).
+# ---------------------------------------------------------------------------------------------
+def _tight(fn, stages=1):
+    def run():
+        global _TIGHT
+        _TIGHT = stages
+        try:
+            out = fn()
+        finally:
+            _TIGHT = False
+        errs = out if isinstance(out[0], tuple) else (out,)
+        return max(e for e, _ in errs), 1.0
+    return run
+
+
+# ViT-B/16 (tile hint 21 = the 256 x 256 persistent tile these layers run on at batch 512)
+CASES["tight_vit_b_qkv_ln_folded"] = _tight(lambda: _ln_gemm_case(2048, 768, 2304, "", 900, tile=21))
+CASES["tight_vit_b_fc1_ln_folded_gelu"] = _tight(lambda: _ln_gemm_case(2048, 768, 3072, "gelu", 901, tile=21))
+CASES["tight_vit_b_fc2_residual"] = _tight(lambda: _gemm_case(2048, 3072, 768, residual=True, tile=21, seed=902))
+CASES["tight_vit_b_proj_residual"] = _tight(lambda: _gemm_case(2048, 768, 768, residual=True, tile=21, seed=903))
+# ResNet-50 stage 1 and stem
+CASES["tight_resnet50_chain_stage1"] = _tight(lambda: _chain_case(6, 56, 56, 64, 256, 1, 904), stages=2)
+CASES["tight_resnet50_chain_stage1_shortcut_conv"] = _tight(lambda: _chain_ds_case(6, 56, 56, 256, 905), stages=2)
+CASES["tight_resnet50_stem_conv_pool"] = _tight(lambda: _stem_pool_case(3, 224, 224, 906), stages=2)
+CASES["tight_resnet50_conv1_relu"] = _tight(lambda: _gemm_case(6 * 3136, 256, 64, act="relu", seed=907))
+CASES["tight_resnet50_conv3_residual_relu"] = _tight(lambda: _gemm_case(6 * 784, 128, 512, act="relu", residual=True, act_after_res=True, seed=908))
+CASES["tight_resnet50_conv3x3_stage2"] = _tight(lambda: _conv_case(6, 28, 28, 128, 128, 3, 1, 1, act="relu", seed=909))
+# Swin-B stage 1 (and ConvNeXt-B stage 1): the one-launch MLP
+CASES["tight_swin_b_mlp_fused_stage1"] = _tight(lambda: _mlp_fused_case(4 * 3136, 910), stages=2)
+CASES["tight_convnext_b_mlp_fused_layerscale"] = _tight(lambda: _mlp_fused_case(2 * 3136, 911, residual_is_x=False, layer_scale=True), stages=2)
+CASES["tight_swin_b_qkv_ln_folded_128"] = _tight(lambda: _ln_gemm_case(4 * 3136, 128, 384, "", 912))
+# EfficientNet-B4 blocks 1-3: expansion + depthwise in one launch, swish epilogues, the SE-gated projection
+CASES["tight_b4_expand_dw_24_144_k3s2"] = _tight(lambda: _expand_dw_case(1, 190, 190, 24, 144, 3, 2, "same", "swish", 913), stages=2)
+CASES["tight_b4_expand_dw_32_192_k3s1"] = _tight(lambda: _expand_dw_case(1, 95, 95, 32, 192, 3, 1, "same", "swish", 914), stages=2)
+CASES["tight_b4_expand_dw_32_192_k5s2"] = _tight(lambda: _expand_dw_case(1, 95, 95, 32, 192, 5, 2, "same", "swish", 915), stages=2)
+CASES["tight_b4_expand_swish_56_336"] = _tight(lambda: _gemm_case(2 * 2304, 56, 336, act="swish", seed=916))
+CASES["tight_b4_se_gated_projection_336_56"] = _tight(lambda: _se_scale_case(2, 2304, 336, 56, 917, bias=True, residual=True))
+CASES["tight_b4_dwconv_k5_336"] = _tight(lambda: _dw_case(1, 48, 48, 336, 5, 1, "same", "swish", 918))
 
 
 def run_case(name):

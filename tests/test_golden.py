@@ -63,12 +63,31 @@ import json  # noqa: E402
 BARS = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_bars.json")))["models"]
 
 
+MINIS_4CH = ("vit_test_model", "cait_test_model")      # embed dim 4: LayerNorm over four values
+
+
+def _logits_bar(name):
+    """2 x observed, CAPPED at the global bar of BASELINE.md section 3.4 (twice that only for the 4-channel minis)."""
+    return min(BARS[name]["logits_bar"], (2 if name in MINIS_4CH else 1) * mc.TOL_LOGITS)
+
+
+def _features_bar(name):
+    return min(BARS[name]["features_bar"], 2 * mc.TOL_LOGITS)
+
+
+def _top1_required(name):
+    """wherever the reference's own top-1 / top-2 margin exceeds the error of that row (recorded with the bars)"""
+    return BARS[name]["observed_min_margin_over_row_err"] > 1.0
+
+
 def test_every_golden_model_has_a_bf16_bar_and_none_is_looser_than_the_global_bar():
     assert sorted(BARS) == MODELS
     for name, b in BARS.items():
         assert 0 < b["logits_bar"] <= 2.2 * b["observed_logits"], name      # 2 x observed, rounded up to two digits
         # the 4-channel minis (vit_test_model, cait_test_model: LayerNorm over 4 values) are the only ones past 5e-2
-        assert b["logits_bar"] <= mc.TOL_LOGITS or name in ("vit_test_model", "cait_test_model"), name
+        assert b["logits_bar"] <= mc.TOL_LOGITS or name in MINIS_4CH, name
+        assert b["observed_logits"] < _logits_bar(name) and b["observed_features_max"] <= _features_bar(name), name
+    assert sum(_top1_required(n) for n in BARS) >= len(BARS) - 2       # every model but the two with sub-error margins
 
 
 @pytest.mark.gpu
@@ -78,8 +97,8 @@ def test_engine_matches_reference_code_path(name):
     model.set_weights(w)
     ref = GOLD[f"{name}/logits"]
     got = model(x).numpy().reshape(ref.shape)
-    assert mc.rel_err(got, ref) <= BARS[name]["logits_bar"]
-    if BARS[name]["top1"]:
+    assert mc.rel_err(got, ref) <= _logits_bar(name)
+    if _top1_required(name):
         assert (got.argmax(-1) == ref.argmax(-1)).all()
 
 
@@ -93,7 +112,7 @@ def test_engine_features_match_reference_code_path(name):
     _, feats = model(x, return_features=True)
     frozen = _features(name)
     assert list(feats.keys()) == frozen
-    tol = BARS[name]["features_bar"]
+    tol = _features_bar(name)
     for k in frozen:
         ref = GOLD[f"{name}/feat/{k}"]
         assert mc.rel_err(feats[k].numpy().reshape(ref.shape), ref) <= tol, k

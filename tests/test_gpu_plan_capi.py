@@ -76,6 +76,43 @@ def test_plan_blob_is_validated():
     assert b"plan" in ffi.lib.tfimm_hip_last_error()
 
 
+@pytest.mark.parametrize("name", ["resnet_test_model_1", "cait_test_model"])
+def test_truncated_and_corrupted_blobs_are_refused_not_followed(name):
+    """Every prefix of a valid blob and a sweep of single corrupted words in its index part must come back as an error code
+    (or as a plan that still passes the parser's range checks) -- never as an out-of-bounds access of the host process:
+    plan_query walks the whole blob, plan_create resolves every reference it holds."""
+    _, x, _, blob = _export(name, 2)
+    lib = ffi.lib
+    info = ffi.PlanInfo()
+    assert lib.tfimm_hip_plan_query(blob, len(blob), C.byref(info)) == 0
+    # (the last constant is padded to a multiple of 256 bytes: a cut inside that padding loses nothing)
+    cuts = sorted(set(list(range(0, 64)) + list(np.linspace(64, len(blob) - 257, 400).astype(int))))
+    for cut in cuts:
+        assert lib.tfimm_hip_plan_query(blob[:cut], cut, C.byref(info)) != 0, f"a blob cut at {cut} of {len(blob)} bytes was accepted"
+    # the index part (slab / constant tables, structs with their relocations, calls, outputs) is the head of the blob, the
+    # constants' bytes follow: corrupt one 32-bit word at a time in the head
+    rng = np.random.default_rng(3)
+    head = min(len(blob) - 4, 12288)
+    ws = torch.empty(int(info.workspace_bytes), dtype=torch.uint8, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    refused = created = 0
+    for pos in rng.integers(28, head, size=120):
+        pos = int(pos) & ~3
+        for word in (b"\xff\xff\xff\xff", b"\xff\xff\xff\x7f", b"\x00\x00\x00\x80"):
+            bad = blob[:pos] + word + blob[pos + 4:]
+            h = C.c_void_p()
+            binfo = ffi.PlanInfo()
+            rc = lib.tfimm_hip_plan_query(bad, len(bad), C.byref(binfo))
+            if rc == 0 and int(binfo.workspace_bytes) <= ws.numel() and created < 24:      # (a caller sizes the workspace from the same blob)
+                created += 1
+                rc = lib.tfimm_hip_plan_create(bad, len(bad), ws.data_ptr(), st, C.byref(h))
+                if rc == 0:
+                    lib.tfimm_hip_plan_destroy(h)
+            if rc != 0:
+                refused += 1
+    assert refused > 0
+
+
 @pytest.mark.skipif(not os.path.exists(HOST), reason="plan_host not built (make -C tensorflow-image-models_amd/csrc)")
 def test_cpp_host_without_python_matches(tmp_path):
     model, x, want, blob = _export("resnet50", 8)

@@ -45,6 +45,23 @@ PY
       timeout 600 python tools/flaky_hunt.py cait_xxs24_224 64 12 3 > $O/flaky_cait.txt 2>&1; tail -n 4 $O/flaky_cait.txt ;;
     tests2)
       TFIMM_BRANCHES=2 timeout 3000 python -m pytest tests -m gpu -q > $O/pytest_gpu_branches2.txt 2>&1; echo "tests(branches=2) rc=$?"; tail -n 8 $O/pytest_gpu_branches2.txt ;;
+    tight)
+      timeout 1200 python - > $O/tight_cases.txt 2>&1 <<PY
+import sys, time
+sys.path[:0] = ["$R", "$R/tensorflow-image-models_amd", "$R/tests"]
+import hip_checks
+for n in sorted(hip_checks.CASES):
+    if n.startswith("tight_"):
+        t = time.time()
+        try:
+            e, tol = hip_checks.run_case(n)
+            print(f"{n:48s} {e:8.3f} of {tol:.1f}   ({time.time() - t:.1f} s)", flush=True)
+        except Exception as ex:
+            print(f"{n:48s} FAILED {type(ex).__name__}: {ex}", flush=True)
+PY
+      cat $O/tight_cases.txt | grep -v amdgpu.ids ;;
+    plancapi)
+      timeout 900 python -m pytest tests/test_gpu_plan_capi.py -x -q > $O/plancapi.txt 2>&1; tail -n 5 $O/plancapi.txt ;;
     memset)
       TFIMM_MEMSET_NODE=1 timeout 900 python tools/flaky_hunt.py efficientnet_b4 256 12 3 > $O/flaky_b4_memset_node.txt 2>&1; tail -n 6 $O/flaky_b4_memset_node.txt ;;
     *) echo "unknown stage $stage" ;;
