@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(NW * 64) attn_resident_kernel(const AttnArgs p
   }
 
   // ---- stage K (16-byte stores)
-  for (int id = (p.dbg & 2) ? nkp * CH : tid; id < nkp * CH; id += NT) {
+  for (int id = (TFIMM_PROBE(p.dbg) & 2) ? nkp * CH : tid; id < nkp * CH; id += NT) {
     const int key = id / CH, c = id - key * CH;
     uint4 ku = make_uint4(0u, 0u, 0u, 0u);
     if (key < p.n && c * 8 < p.hd) {
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(NW * 64) attn_resident_kernel(const AttnArgs p
     Ks[k_slot<HD>(key, c)] = ku;
   }
   // ---- stage V row-major (16-byte stores, same coalescing as K)
-  for (int id = (p.dbg & 2) ? nkp * CH : tid; id < nkp * CH; id += NT) {
+  for (int id = (TFIMM_PROBE(p.dbg) & 2) ? nkp * CH : tid; id < nkp * CH; id += NT) {
     const int key = id / CH, c = id - key * CH;
     uint4 vu = make_uint4(0u, 0u, 0u, 0u);
     if (key < p.n && c * 8 < p.hd) {
@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(NW * 64) attn_resident_kernel(const AttnArgs p
   const bool two = TQ == 2 && (wave + NW) * 16 < p.n;   // second tile present (wave-uniform)
 
   if (wave * 16 < p.n) {
-    for (int kb = (p.dbg & 1) ? nkb : 0; kb < nkb; ++kb) {
+    for (int kb = (TFIMM_PROBE(p.dbg) & 1) ? nkb : 0; kb < nkb; ++kb) {
       // ---- raw scores S^T[key][q] of the 4 key tiles of this block, both query tiles
       f32x4 acc[TQ][4];
 #pragma unroll
@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(NW * 64) attn_stream_kernel(const AttnArgs p, 
       if (KS > 1) qf[TQ - 1][KS - 1] = __builtin_bit_cast(bf16x8, pre.q11);
     }
     __syncthreads();
-    if (item + (int)gridDim.x < items && !(p.dbg & 2))          // in flight during the arithmetic below
+    if (item + (int)gridDim.x < items && !(TFIMM_PROBE(p.dbg) & 2))          // in flight during the arithmetic below
       attn_fetch_item<HD, PF, KS, NT, TQ>(p, item + gridDim.x, tid, qi[0], qi[TQ - 1], g, pre);
 
     const int h = item % p.heads, seq = item / p.heads;
@@ -673,7 +673,7 @@ __global__ void __launch_bounds__(NW * 64) attn_stream_kernel(const AttnArgs p, 
       // sub-tiles hold keys (n = 197: one of four): the score MFMAs, the exponentials and the P.V k-steps of the others are
       // skipped (wave-uniform branches); what they would have contributed are exact zeros (P = 0), so the result is
       // bit-identical to multiplying the padding.
-      for (int kb = (p.dbg & 1) ? nkb : 0; kb < nkb; ++kb) {
+      for (int kb = (TFIMM_PROBE(p.dbg) & 1) ? nkb : 0; kb < nkb; ++kb) {
         const int nt = min(4, (p.n - kb * 64 + 15) >> 4);      // wave-uniform
         const bool PART = nt < 4 || kb * 64 + 64 > p.n;
         f32x4 acc[TQ][4];

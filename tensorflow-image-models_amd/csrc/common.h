@@ -11,6 +11,15 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef uint16_t bf16_t;
 
+// Measurement / ablation switches inside kernels (TFIMM_GEMM_DBG, TFIMM_CHAIN_DBG, TFIMM_ATTN_DBG, ...: skip a phase, redirect an
+// operand, record s_memtime stamps) exist only in probe builds (-DTFIMM_PROBE_HOOKS, tools/probes/build_dbg_libs.sh): in the
+// product library the flag word reads as 0 at compile time and the code behind it is gone.
+#if defined(TFIMM_PROBE_HOOKS) || defined(TFIMM_STREAM_DBG)
+#define TFIMM_PROBE(x) (x)
+#else
+#define TFIMM_PROBE(x) 0
+#endif
+
 // ---- error plumbing (host) ---------------------------------------------------------
 void tfimm_set_error(const char* fmt, ...);
 #define TFIMM_FAIL(code, ...)        \

@@ -253,8 +253,8 @@ __global__ void __launch_bounds__(256, 2) gemm_chain_kernel(const ChainArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias1[0][0]), "+v"(bias1[0][3]), "+v"(bias1[TN1 - 1][0]), "+v"(bias1[TN1 - 1][3])::"memory");
   }
 
-  if (p.dbg & 8) {
-    const int n = ((blockIdx.x >> 3) & 7) * (p.dbg >> 8);
+  if (TFIMM_PROBE(p.dbg) & 8) {
+    const int n = ((blockIdx.x >> 3) & 7) * (TFIMM_PROBE(p.dbg) >> 8);
     for (int i = 0; i < n; ++i) asm volatile("s_sleep 8");
   }
   // ---- prime the pipeline: strip of the first tile, weight steps 0..2
@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(256, 2) gemm_chain_kernel(const ChainArgs p) {
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
           const unsigned off = res_off0 + (unsigned)(it * RPI) * ldr2 + (unsigned)(g * WTN * 2);
-          rres[u & 1][g][it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, (int)((p.dbg & 4) ? kOobOffset : off), 0, 0));
+          rres[u & 1][g][it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, (int)((TFIMM_PROBE(p.dbg) & 4) ? kOobOffset : off), 0, 0));
         }
         }
         braw[u & 1][g][0] = *reinterpret_cast<const float4*>(p.b2 + u * BN2 + g * WTN + e_c8 * 8);
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(256, 2) gemm_chain_kernel(const ChainArgs p) {
         for (int j = 0; j < TN1; ++j) fb[j] = __builtin_bit_cast(bf16x8, sB[lds_slot(j * 32 + frow, ks * 2 + fhi)]);
 #pragma unroll
         for (int j = 0; j < TN1; ++j)
-          if (!(p.dbg & 2)) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa, acc1[j], 0, 0, 0);
+          if (!(TFIMM_PROBE(p.dbg) & 2)) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa, acc1[j], 0, 0, 0);
       }
       rotate();
     };
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(256, 2) gemm_chain_kernel(const ChainArgs p) {
       rotate();
 
       // ---- epilogue 2 (per wave; dedicated staging block, so it overlaps the other waves' work and the prefetch)
-      const bool skip_epi = (p.dbg & 1) != 0;
+      const bool skip_epi = (TFIMM_PROBE(p.dbg) & 1) != 0;
 #pragma unroll
       for (int g = 0; g < PASSES; ++g) {
         // hipcc pads no hazard in front of an asm statement: an MFMA result needs up to 18 wait states before a DS

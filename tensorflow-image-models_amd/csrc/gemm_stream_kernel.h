@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
         // probe build (-DTFIMM_STREAM_DBG), TFIMM_GEMM_DBG & 128: every tile fetches the FIRST activation panel -- what the loop does when
         // the A operand always hits in L2
 #ifdef TFIMM_STREAM_DBG
-        const int msrc = (pa.dbg & 128) ? r : m;
+        const int msrc = (TFIMM_PROBE(pa.dbg) & 128) ? r : m;
 #else
         const int msrc = m;
 #endif
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
       const int chunk = lpc ^ ((r >> 1) & 7);
       const int n = n0 + r;
 #ifdef TFIMM_STREAM_DBG
-      const int nsrc = (pa.dbg & 256) ? r : n;      // measurement only: every tile fetches the first weight panel
+      const int nsrc = (TFIMM_PROBE(pa.dbg) & 256) ? r : n;      // measurement only: every tile fetches the first weight panel
 #else
       const int nsrc = n;
 #endif
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   bool stores_pending = false;   // the previous step ended an interior tile: its stores may still be in flight
   int stamp_i = 0;
   auto stamp = [&]() __attribute__((always_inline)) {
-    if ((pa.dbg & 64) && blockIdx.x == 0 && lane == 0 && stamp_i < 60) pa.dbg_ptr[wave * 64 + stamp_i++] = __builtin_readcyclecounter();
+    if ((TFIMM_PROBE(pa.dbg) & 64) && blockIdx.x == 0 && lane == 0 && stamp_i < 60) pa.dbg_ptr[wave * 64 + stamp_i++] = __builtin_readcyclecounter();
   };
 
   for (int tile = t_first; tile < t_hi; tile += t_step) {
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
       unsigned off = res_off0 + (unsigned)d * ldr2;
       off -= (rm0 + d >= resmod_eff) ? res_wrap : 0u;
 #ifdef TFIMM_STREAM_DBG   // probe build: TFIMM_GEMM_DBG & 2 = every residual load out of range (returns zeros, no memory access)
-      if (pa.dbg & 2) off = kOobOffset;
+      if (TFIMM_PROBE(pa.dbg) & 2) off = kOobOffset;
 #endif
       rres[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, (int)off, 0, 0));
     };
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
       // issue order, and the only ones younger than that DMA are the previous tile's epilogue
       // (>= TM*ITS store instructions for an interior tile): leave exactly those in flight.
 #ifdef TFIMM_STREAM_DBG   // probe build: TFIMM_GEMM_DBG & 1 = no counted wait (every step drains all VMEM)
-      if (VEC && stores_pending && !(pa.dbg & 1)) {
+      if (VEC && stores_pending && !(TFIMM_PROBE(pa.dbg) & 1)) {
 #else
       if (VEC && stores_pending) {
 #endif
@@ -732,7 +732,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   // the last step's (all out-of-range) prefetch must have landed before this workgroup's LDS is released
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef TFIMM_STREAM_DBG   // probe build: TFIMM_GEMM_DBG & 4 = all waves leave together, after everything of every wave has landed
-  if (pa.dbg & 4) {
+  if (TFIMM_PROBE(pa.dbg) & 4) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }

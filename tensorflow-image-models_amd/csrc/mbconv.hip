@@ -193,7 +193,7 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
               const int q = 2 * h + (e >> 1), r = (e & 1) * 2;
               v[e] = tfimm_f32x2{acc[q * 4 + r] + bq[q][r], acc[q * 4 + r + 1] + bq[q][r + 1]};
             }
-            if (!(p.dbg & 4)) act8p(v, a1);
+            if (!(TFIMM_PROBE(p.dbg) & 4)) act8p(v, a1);
             if (px < G::NPX) {
 #pragma unroll
               for (int qq = 0; qq < 2; ++qq) {
@@ -255,13 +255,13 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
         tfimm_f32x2 v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (r0 + e < RPTL) ? acc[(r0 + e < RPTL) ? r0 + e : 0] : tfimm_f32x2{0.f, 0.f};
-        if (!(p.dbg & 2)) act8p(v, a2);
+        if (!(TFIMM_PROBE(p.dbg) & 2)) act8p(v, a2);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (r0 + e < RPTL) {
             const uint32_t pk = pack_bf2(v[e][0], v[e][1]);
             if (cok && oybl + r0 + e < p.OH) {
-              if (!(p.dbg & 1)) *reinterpret_cast<uint32_t*>(yb + (size_t)(r0 + e) * p.OW * p.C) = pk;
+              if (!(TFIMM_PROBE(p.dbg) & 1)) *reinterpret_cast<uint32_t*>(yb + (size_t)(r0 + e) * p.OW * p.C) = pk;
               // the squeeze sees the stored (bf16-rounded) activations, as in tfimm_hip_dwconv
               tot += tfimm_f32x2{__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)};
             }

@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(kThreads, 2) stem_pool_kernel(const StemArgs p
     for (int s = s_first; s < s_end; ++s) {
       // step s: convolution rows 2s, 2s+1 from input rows 4s .. 4s+8 (groups s, s+1, s+2) -> pooled row s.
       // The next step's new rows (group s + 3) are requested now and written to the ring after the arithmetic.
-      const bool pf = !(p.dbg & 4);
+      const bool pf = !(TFIMM_PROBE(p.dbg) & 4);
       StemPre<IN> pre0 = {}, pre1 = {};
       if (pf) pre0 = fetch(s + 3, tid);
       if (pf && tid + kThreads < kFetch) pre1 = fetch(s + 3, tid + kThreads);
@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(kThreads, 2) stem_pool_kernel(const StemArgs p
         store_block(acc[0], mb);
         if (nblk > 1) store_block(acc[1], mb + 1);
       };
-      const int mb_end = (p.dbg & 2) ? 0 : mblocks;
+      const int mb_end = (TFIMM_PROBE(p.dbg) & 2) ? 0 : mblocks;
       bf16x8 xf[2][2][7];          // [buffer][block of the pair][kernel row]
       if (mb_end > 0) load_blocks(xf[0], 0, mb_end > 1 ? 2 : 1);
 #pragma unroll 1
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(kThreads, 2) stem_pool_kernel(const StemArgs p
       if (tid + kThreads < kFetch) *slot_ptr(s + 3, tid + kThreads) = stem_pack<IN>(pre1);
       __syncthreads();     // this step's two convolution rows are in LDS
 
-      if (s >= s_begin && !(p.dbg & 1)) {
+      if (s >= s_begin && !(TFIMM_PROBE(p.dbg) & 1)) {
         // pooled row s: 3x3 window, stride 2, one zero row / column of padding on top / left (values are >= 0 after
         // the ReLU, so padding never wins and bf16 order is unsigned-integer order)
         const int py = s;
