@@ -112,12 +112,13 @@ int pick_dma_tile(const tfimm_gemm_desc& d) {
 // ceil(tiles / slots) rounds; score = efficiency x useful area x fill of those rounds.
 int pick_stream_tile(const tfimm_gemm_desc& d, const int* occ) {
   if (d.tile_hint > 20 && d.tile_hint <= 20 + TFIMM_GEMM_STREAM_NUM_TILES) return d.tile_hint - 21;
+#ifdef TFIMM_PROBE_HOOKS
   {
-    // debugging aid: TFIMM_GEMM_AUTO_TILE=k sends every launch WITHOUT a hint to stream tile k (0-based) -- used to find which
-    // tile kernel disturbs a co-resident workgroup of another kernel (profiles/NOTES_r03.md section 9)
+    // probe builds: TFIMM_GEMM_AUTO_TILE=k sends every launch WITHOUT a hint to stream tile k (0-based)
     static const int forced = getenv("TFIMM_GEMM_AUTO_TILE") ? atoi(getenv("TFIMM_GEMM_AUTO_TILE")) : -1;
     if (forced >= 0 && forced < TFIMM_GEMM_STREAM_NUM_TILES && forced != 7) return forced;
   }
+#endif
   static const double eff[TFIMM_GEMM_STREAM_NUM_TILES] = {1.00, 0.90, 0.75, 0.70, 0.55, 0.90, 0.75, 0.0, 0.40, 0.0};
   const int cus = num_cu();
   int best = 2;
@@ -149,6 +150,12 @@ bool stream_disabled() {
   return v == 1;
 }
 
+bool strip_conv_enabled() {
+  static int v = -1;
+  if (v < 0) v = (getenv("TFIMM_STRIP_CONV") && atoi(getenv("TFIMM_STRIP_CONV")) == 0) ? 0 : 1;
+  return v == 1;
+}
+
 bool dma_disabled() {
   static int v = -1;
   if (v < 0) {
@@ -159,6 +166,9 @@ bool dma_disabled() {
 }
 
 }  // namespace
+
+// csrc/conv_strip.hip
+int tfimm_launch_conv_strip(const tfimm_gemm::GemmArgs& g, int64_t a_bytes, int64_t w_bytes, int64_t out_bytes, int num_cu, hipStream_t stream);
 
 extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
   if (!dp) TFIMM_FAIL(TFIMM_EINVAL, "gemm: null descriptor");
@@ -247,6 +257,18 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
     g.out_vec = ((d.ldc & 3) == 0) && (((uintptr_t)d.out & 15) == 0);
   else
     g.out_vec = ((d.ldc & 3) == 0) && (((uintptr_t)d.out & 7) == 0);
+
+  // ---- 3x3 / stride 1 / pad 1, 128 -> 128 channels, rows of at most 31 pixels (ResNet-50 stage 2): the input-strip kernel
+  //      (csrc/conv_strip.hip).  Tile hint 31 asks for it, hint 0 takes it unless TFIMM_STRIP_CONV=0; any other hint keeps
+  //      the implicit-GEMM tiles (the tuner's candidates).
+  if (kmode == K_CONV && d.KH == 3 && d.KW == 3 && d.stride == 1 && g.stride_w == 1 && d.pad_t == 1 && d.pad_l == 1 && d.OH == d.H &&
+      d.OW == d.W && d.Cin == 128 && g.cpitch == 128 && d.N == 128 && !d.residual && !d.out_f32 && g.out_vec16 && d.remap_in == 0 &&
+      !d.ln_stats && d.W <= 31 && d.ldw >= d.K && (d.tile_hint == 31 || (d.tile_hint == 0 && strip_conv_enabled()))) {
+    const int64_t a_bytes = ((int64_t)d.B * d.H * d.W) * 128 * 2, w_bytes = (int64_t)d.N * d.ldw * 2;
+    const int64_t out_bytes = ((int64_t)(d.M - 1) * d.ldc + d.N) * 2;
+    if (a_bytes <= 0x7fffff00LL && w_bytes <= 0x7fffff00LL && out_bytes <= 0x7fffff00LL)
+      return tfimm_launch_conv_strip(g, a_bytes, w_bytes, out_bytes, num_cu(), (hipStream_t)stream);
+  }
 
   // ---- persistent LDS-DMA family (default): same operand requirements as the DMA family below
   {

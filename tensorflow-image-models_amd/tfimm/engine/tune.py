@@ -10,13 +10,14 @@
 Hints: 0 = library cost model, 11..16 = one-tile-per-workgroup LDS-DMA tiles, 21..26 =
 persistent LDS-DMA tiles (ids: 256x256, 256x128, 128x128, 256x64, 128x64, 128x256; 27 = 256x64 with
 64x64 wave tiles; 28 = 256x256 with the four-stage ring of gemm_pipe_kernel.h; 29 = 256x32 for narrow outputs;
-30 = 256x128 with two co-resident four-wave workgroups per CU, gemm_duo_kernel.h).
+30 = 256x128 with two co-resident four-wave workgroups per CU, gemm_duo_kernel.h; 31 = the input-strip kernel for
+3x3 / stride 1 convolutions of 128 -> 128 channels, csrc/conv_strip.hip -- any other shape falls back to the cost model).
 """
 import json
 import os
 
 _PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tune.json")
-CANDIDATES = (0, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 11, 12, 13, 14, 15, 16)
+CANDIDATES = (0, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 11, 12, 13, 14, 15, 16)
 # a layer with a folded LayerNormalization runs on the persistent tiles only (the library ignores any other hint for it)
 LN_CANDIDATES = (0, 21, 22, 23, 24, 25, 26, 27, 29, 30)
 TABLE = {}

@@ -1376,6 +1376,40 @@ CASES["tight_b4_se_gated_projection_336_56"] = _tight(lambda: _se_scale_case(2, 
 CASES["tight_b4_dwconv_k5_336"] = _tight(lambda: _dw_case(1, 48, 48, 336, 5, 1, "same", "swish", 918))
 
 
+# ---------------------------------------------------------------------------------------------
+# 3x3 / stride 1, 128 -> 128 channels on the input-strip kernel (csrc/conv_strip.hip, tile hint 31): against the oracle, and
+# bit for bit against the implicit-GEMM tile it replaces (same operand roles, same order of the K reduction)
+# ---------------------------------------------------------------------------------------------
+def _strip_conv_case(B, Hh, Ww, seed, act="relu"):
+    import hip_ops as H
+    r = _rng(seed)
+    C = 128
+    x = _bf(r.standard_normal((B, Hh, Ww, C)))
+    kern = (r.standard_normal((3, 3, C, C)) / math.sqrt(9 * C)).astype(np.float32)
+    scale, shift = r.uniform(0.5, 1.5, C).astype(np.float32), r.standard_normal(C).astype(np.float32)
+    wt, bias, K, mode = pack.pack_conv(kern, scale, shift, C)
+    y = O.conv2d(O.zero_pad2d(torch.from_numpy(x), 1), torch.from_numpy(_bf(kern * scale.reshape(1, 1, 1, -1))), None) + torch.from_numpy(shift)
+    y = O.activation(y, act).numpy()
+    xd, wd, bd = H.dev_bf16(x), H.dev_bits(wt), H.dev_f32(bias)
+    conv = dict(mode=mode, B=B, H=Hh, W=Ww, Cin=C, KH=3, KW=3, stride=1, pad_t=1, pad_l=1, OH=Hh, OW=Ww)
+    got = H.gemm(xd, wd, C, K, bias=bd, act=act, conv=conv, tile_hint=31)
+    other = H.gemm(xd, wd, C, K, bias=bd, act=act, conv=conv, tile_hint=24)
+    H.sync()
+    if not torch.equal(got.view(torch.int16), other.view(torch.int16)):
+        return float("inf"), TOL_BF16
+    return _err(_cpu(got).reshape(B, Hh, Ww, C), y), TOL_BF16
+
+
+CASES["strip_conv_28x28_b6"] = lambda: _strip_conv_case(6, 28, 28, 400)                     # ResNet-50 stage 2: 37 tiles, the last one ragged
+CASES["strip_conv_odd_17x23"] = lambda: _strip_conv_case(3, 17, 23, 401)                    # every border case of the tap mask, images inside tiles
+CASES["strip_conv_31_wide"] = lambda: _strip_conv_case(2, 9, 31, 402)                       # the widest row the strip holds
+CASES["strip_conv_tiny_5x7"] = lambda: _strip_conv_case(1, 5, 7, 403)                       # one partial tile, strip mostly out of range
+CASES["strip_conv_1x1_images"] = lambda: _strip_conv_case(200, 1, 1, 404)                   # every tap but the centre masked
+CASES["strip_conv_multiround_b130"] = lambda: _strip_conv_case(130, 28, 28, 405)            # 797 tiles: two per workgroup on most CUs
+CASES["strip_conv_swish_14x14"] = lambda: _strip_conv_case(9, 14, 14, 406, act="swish")
+CASES["tight_resnet50_conv3x3_stage2_strip"] = _tight(lambda: _strip_conv_case(6, 28, 28, 407))
+
+
 def run_case(name):
     out = CASES[name]()
     err, tol = out

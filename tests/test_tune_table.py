@@ -30,11 +30,14 @@ def test_key_covers_shape_epilogue_and_ln_flavour():
 def test_committed_table_is_well_formed():
     table = json.load(open(TABLE))
     assert len(table) >= 150
-    valid = {0} | set(range(1, 7)) | set(range(11, 17)) | set(range(21, 31))
+    valid = {0} | set(range(1, 7)) | set(range(11, 17)) | set(range(21, 32))
     for key, hint in table.items():
         fields = key[:-3].split(":") if key.endswith(":ln") else key.split(":")
         assert len(fields) == 16 and all(f.lstrip("-").isdigit() for f in fields), key
         assert hint in valid, (key, hint)
+        if hint == 31:      # the input-strip kernel: 3x3 / stride 1 convolutions of 128 -> 128 channels, rows of at most 31 pixels
+            f = fields
+            assert (f[0], f[2], f[3], f[8], f[9], f[10], f[11], f[12]) == ("1", "128", "1152", "128", "3", "3", "1", "0") and int(f[7]) <= 31, key
         if key.endswith(":ln"):
             # only the persistent LDS-DMA tiles carry the LayerNorm epilogue (28 = the deep-ring schedule does not)
             assert hint == 0 or (21 <= hint <= 30 and hint != 28), (key, hint)

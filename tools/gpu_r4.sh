@@ -60,6 +60,44 @@ for n in sorted(hip_checks.CASES):
             print(f"{n:48s} FAILED {type(ex).__name__}: {ex}", flush=True)
 PY
       cat $O/tight_cases.txt | grep -v amdgpu.ids ;;
+    strip)
+      timeout 900 python - > $O/strip.txt 2>&1 <<PY
+import sys, time
+sys.path[:0] = ["$R", "$R/tensorflow-image-models_amd", "$R/tests"]
+import numpy as np, torch
+import hip_checks, hip_ops as H
+from tfimm.engine import pack
+for n in sorted(hip_checks.CASES):
+    if "strip_conv" in n:
+        try:
+            e, tol = hip_checks.run_case(n)
+            print(f"{n:44s} {e:10.3e} of {tol:.1e}", flush=True)
+        except Exception as ex:
+            print(f"{n:44s} FAILED {type(ex).__name__}: {ex}", flush=True)
+# timing at the scored shape (ResNet-50 stage 2, batch 256 and 128): M = 200704 / 100352, K = 1152, N = 128
+r = np.random.default_rng(0)
+C = 128
+kern = (r.standard_normal((3, 3, C, C)) / 34).astype(np.float32)
+wt, bias, K, mode = pack.pack_conv(kern, np.ones(C, np.float32), np.zeros(C, np.float32), C)
+wd, bd = H.dev_bits(wt), H.dev_f32(bias)
+for B in (256, 128):
+    xs = [torch.randn(B * 28 * 28, C, device="cuda").to(torch.bfloat16) for _ in range(3)]
+    outs = [torch.empty(B * 28 * 28, C, dtype=torch.bfloat16, device="cuda") for _ in range(3)]
+    conv = dict(mode=mode, B=B, H=28, W=28, Cin=C, KH=3, KW=3, stride=1, pad_t=1, pad_l=1, OH=28, OW=28)
+    for hint in (31, 24, 22, 23, 21, 30):
+        for i in range(3):
+            H.gemm(xs[i], wd, C, K, bias=bd, act="relu", conv=conv, tile_hint=hint, out=outs[i])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for it in range(30):
+            H.gemm(xs[it % 3], wd, C, K, bias=bd, act="relu", conv=conv, tile_hint=hint, out=outs[it % 3])
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 30 * 1e3
+        print(f"B={B} hint {hint:2d}: {us:7.1f} us  {2.0 * B * 784 * K * C / us / 1e6:6.1f} TFLOP/s", flush=True)
+PY
+      grep -v amdgpu.ids $O/strip.txt ;;
     plancapi)
       timeout 900 python -m pytest tests/test_gpu_plan_capi.py -x -q > $O/plancapi.txt 2>&1; tail -n 5 $O/plancapi.txt ;;
     memset)
