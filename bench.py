@@ -109,14 +109,15 @@ def measured_traffic(workload, batch):
     (FETCH_SIZE / WRITE_SIZE need their own profiler passes and cannot be collected from inside this process):
     tools/gpu_traffic.sh.  Returns (bytes per launch, source) -- a constant from that profile, not a counter of this run;
     None when no profile of this workload / batch exists."""
-    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
-    if batch == WORKLOADS.get(workload, {}).get("batch") and os.path.exists(path):
-        with open(path) as f:
-            t = json.load(f).get("workloads", {}).get(workload)
-        if t and "hbm_bytes_per_launch" in t:
-            return (round(t["hbm_bytes_per_launch"]),
-                    "from committed profile profiles/r03_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
-                    "eager launches; not measured in this run)")
+    for rel in ("r04_traffic.json", "r03_traffic.json"):            # the newest committed profile
+        path = os.path.join(ROOT, "profiles", rel)
+        if batch == WORKLOADS.get(workload, {}).get("batch") and os.path.exists(path):
+            with open(path) as f:
+                t = json.load(f).get("workloads", {}).get(workload)
+            if t and "hbm_bytes_per_launch" in t:
+                return (round(t["hbm_bytes_per_launch"]),
+                        f"from committed profile profiles/{rel} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                        "eager launches; not measured in this run)")
     return None, None
 
 

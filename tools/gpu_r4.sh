@@ -4,6 +4,7 @@
 #   rccl    bench.py --gpus 1 --spawn --backend nccl (world = 1 through RCCL) + the multirank tests
 #   bench   the default bench line (ResNet-50 + the `also` workloads)
 #   tests   pytest -m gpu
+#   profiles rocprofv3 kernel stats, per-op profiles, MFMA-busy / wave-state and HBM-traffic PMC passes of the scored workloads
 #   cait    CaiT under parallel branches: TFIMM_BRANCHES=2 tests + flaky/branch hunts
 #   tests2  pytest -m gpu with every model test on two parallel branches (TFIMM_BRANCHES=2)
 #   memset  the round-3 memset-node observation again (TFIMM_MEMSET_NODE=1 flaky hunt on EfficientNet-B4)
@@ -98,6 +99,26 @@ for B in (256, 128):
         print(f"B={B} hint {hint:2d}: {us:7.1f} us  {2.0 * B * 784 * K * C / us / 1e6:6.1f} TFLOP/s", flush=True)
 PY
       grep -v amdgpu.ids $O/strip.txt ;;
+    profiles)
+      # the round's evidence from ONE box: rocprofv3 kernel stats + per-op profiles + MFMA-busy / wave-state PMC passes of the four
+      # scored workloads, the HBM-traffic PMC passes; summaries under gpurun_out/r4/ (copy to profiles/r04_*)
+      cd /tmp
+      for m in resnet50 vit_base_patch16_224 swin_base_patch4_window7_224 efficientnet_b4; do
+        rm -rf $O/prof_$m
+        timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$m -o $m -- python $R/bench.py --workload $m --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-kernel-events --extra "" > $O/prof_$m.log 2>&1; echo "rocprof $m rc=$?"
+        f=$(find $O/prof_$m -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${m}_kernel_stats.csv && head -4 $O/${m}_kernel_stats.csv | cut -c1-170
+        rm -rf $O/prof_$m
+      done
+      cd $R
+      for m in resnet50 vit_base_patch16_224 swin_base_patch4_window7_224 efficientnet_b4; do
+        timeout 300 python tools/op_profile.py $m > $O/opprof_$m.log 2>&1; echo "opprof $m rc=$?"; cp gpurun_out/opprof_$m.txt $O/ 2>/dev/null; head -1 $O/opprof_$m.txt
+      done
+      for m in resnet50 vit_base_patch16_224 swin_base_patch4_window7_224 efficientnet_b4; do
+        bash tools/gpu_mfma_busy.sh $m > /dev/null 2>&1; cp gpurun_out/mfma_busy_$m.txt $O/ 2>/dev/null; head -6 $O/mfma_busy_$m.txt | cut -c1-170
+        bash tools/gpu_pipe_busy.sh $m > /dev/null 2>&1; cp gpurun_out/pipe_busy_$m.txt $O/ 2>/dev/null
+      done
+      bash tools/gpu_traffic.sh > $O/traffic.log 2>&1; tail -14 $O/traffic.log; cp gpurun_out/traffic.json $O/traffic.json
+      rm -rf gpurun_out/traffic_* ;;
     plancapi)
       timeout 900 python -m pytest tests/test_gpu_plan_capi.py -x -q > $O/plancapi.txt 2>&1; tail -n 5 $O/plancapi.txt ;;
     memset)
