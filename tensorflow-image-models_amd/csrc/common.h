@@ -46,6 +46,20 @@ void tfimm_set_error(const char* fmt, ...);
     TFIMM_LAUNCH_CHECK();                 \
   } while (0)
 
+// ---- a workgroup barrier behind which OTHER waves overwrite LDS that THIS wave has been reading ----------------------
+// (an epilogue staging block that aliases the operand stage consumed last).  The wave's own LDS reads must be COMPLETE when it
+// signals arrival.  __builtin_amdgcn_s_barrier() does not order them: it is not a memory operation for hipcc, which issues
+// the last k-slice's ds_read_b128 in front of it and waits for them (s_waitcnt lgkmcnt) where their values are consumed --
+// the scheduler is free to put those MFMAs, and the wait, BEHIND the barrier.  Another wave's staging writes then race the
+// reads still in flight: one fragment row of a tile multiplied with staged output values (found in round 4 on the K = 64 cases
+// of the four-wave tiles, 1-7 of 8 launches, once the s_memtime stamp hook between loop and epilogue -- a branch, i.e. a
+// scheduling boundary -- was compiled out of product builds: profiles/NOTES_r04.md section 2).
+__device__ __forceinline__ void tfimm_lds_reuse_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // ---- bf16 <-> fp32 -----------------------------------------------------------------
 __device__ __forceinline__ float bf2f(uint32_t h) { return __uint_as_float(h << 16); }
 // fp32 -> bf16, round-to-nearest-even (hardware v_cvt_pk_bf16_f32 on gfx950; NaN stays NaN)

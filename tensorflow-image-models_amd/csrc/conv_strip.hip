@@ -195,8 +195,7 @@ __global__ void __launch_bounds__(256, 2) conv_strip_kernel(const StripArgs pa) 
     }
 
     // ---- epilogue: the strip is dead once every wave has left the last step
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    tfimm_lds_reuse_barrier();
     char* const sE = sStrip + wave * 8192;            // this wave's 64 pixels x 64 channels, bf16: 128 bytes per pixel row
 #pragma unroll
     for (int i = 0; i < 2; ++i)

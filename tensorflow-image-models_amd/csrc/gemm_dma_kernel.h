@@ -177,8 +177,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_dma_kernel(const G
   }
 
   // ---- epilogue through LDS: pass `i` handles row-tile i of every wave row (WAVES_M * 32 rows)
-  __builtin_amdgcn_s_barrier();   // all MFMA reads of the last stage are done: LDS is free
-  asm volatile("" ::: "memory");
+  tfimm_lds_reuse_barrier();   // all MFMA reads of the last stage are done: LDS is free
   constexpr int CROW = BN + 4;                       // fp32 row stride (+16 B: conflict-free b128 writes)
   float* sC = reinterpret_cast<float*>(smem);
   constexpr int PASS_ROWS = WAVES_M * 32;

@@ -323,8 +323,7 @@ __global__ void __launch_bounds__(256, 2) gemm_duo_kernel(const GemmStreamArgs p
     if (nk == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE + (FAST ? 0 : ITS)) : "memory");
     // ---- epilogue through the stage of the k-tile consumed last (cur - 1): every wave must be done reading it; its
     //      refill is issued behind the next step's barrier, i.e. after every wave finished this epilogue
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    tfimm_lds_reuse_barrier();
     char* const sE = smem + (cur >= 1 ? cur - 1 : NS - 1) * STAGE + wave * 4096;   // 4 KiB per wave
 
     if constexpr (FAST) {

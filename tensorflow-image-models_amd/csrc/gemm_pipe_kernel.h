@@ -241,8 +241,7 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmStreamArgs pa)
 
     // ---- epilogue through the buffer of the k-tile consumed last (stage cur-1): every wave must be done
     //      reading it; its refill is issued behind the next iteration's barrier, i.e. after all epilogues
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    tfimm_lds_reuse_barrier();
     float* sEw = reinterpret_cast<float*>(smem + ((cur + NS - 1) & (NS - 1)) * STAGE + wave * EPI_WAVE);
 
     // per-tile epilogue state (see the stream kernel's VEC epilogue for the addressing scheme)

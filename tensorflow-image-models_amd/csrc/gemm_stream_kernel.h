@@ -478,8 +478,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
     //      after the next step's barrier, i.e. after every wave finished this epilogue.
     float* sEw;
     if (G::EPI_ALIAS) {
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
+      tfimm_lds_reuse_barrier();     // (with every fragment read of this wave COMPLETE: see common.h)
       sEw = reinterpret_cast<float*>(smem + (cur ^ 1) * STAGE + wave * G::EPI_WAVE);
     } else {
       sEw = reinterpret_cast<float*>(smem + 2 * STAGE + wave * G::EPI_WAVE);

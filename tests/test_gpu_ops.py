@@ -29,6 +29,23 @@ def test_conv_chain_splits_oversize_batches_into_image_chunks():
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
 
 
+@pytest.mark.parametrize("tile", [23, 25, 29, 27, 22])
+def test_one_ktile_tiles_are_right_on_every_launch(tile):
+    """K = 64 on the four-wave persistent tiles (128 x 128, 128 x 64, 256 x 32; 256 x 64 and the eight-wave 256 x 128 as
+    controls), twelve launches each.  With a single k-tile the epilogue starts right behind the only k-step: the barrier in
+    front of the staging block that aliases the operand stage used to be crossed with the last slice's fragment reads still in
+    flight (hipcc had moved their s_waitcnt behind the bare s_barrier), and another wave's staging writes replaced one
+    fragment row -- one output row of a tile garbage in 1-7 of 8 launches (profiles/NOTES_r04.md section 2;
+    tfimm_lds_reuse_barrier in csrc/common.h).  The single-launch cases gemm_stream_k64_tile* catch it only sometimes."""
+    import hip_checks
+    bad = []
+    for rep in range(12):
+        err, tol = hip_checks.run_case(f"gemm_stream_k64_tile{tile:02d}")
+        if not err <= tol:
+            bad.append((rep, err))
+    assert not bad, f"tile hint {tile}: {len(bad)} of 12 launches wrong: {bad[:3]}"
+
+
 @pytest.mark.parametrize("K,N,act,residual", [(56, 336, "swish", False), (64, 384, "", True), (40, 128, "relu", False)])
 def test_two_ktile_tiles_of_the_duo_kernel_are_reproducible(K, N, act, residual):
     """Tile hint 30 with exactly TWO 32-wide k-tiles (EfficientNet-B4's K = 56 expansions): the tile's bias table is requested
