@@ -97,8 +97,7 @@ __global__ void __launch_bounds__(256, 2) conv_strip_kernel(const StripArgs pa) 
   for (int tile = t_first; tile < t_hi; tile += t_step) {
     const int m0 = tile * STRIP_BM;
     // every wave is done with the previous tile's epilogue block (it aliases the strip) and with both weight stages
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    tfimm_lds_reuse_barrier();
     issue_strip(m0);
     issue_w(0, 0);
 
@@ -159,8 +158,7 @@ __global__ void __launch_bounds__(256, 2) conv_strip_kernel(const StripArgs pa) 
       for (int half = 0; half < 2; ++half) {
         const int step = tap * 2 + half;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this step's weights (and, first step, the strip) have landed
-        __builtin_amdgcn_s_barrier();                            // ... everyone's; the other stage is free again
-        asm volatile("" ::: "memory");
+        tfimm_lds_reuse_barrier();                               // ... everyone's; the other stage is free again
         if (step + 1 < 18) issue_w(step + 1, (step + 1) & 1);
         const unsigned wst = ring_base + (unsigned)((step & 1) * STRIP_STAGE);
         u32x4 fx[2][2], fw[2][2];

@@ -321,8 +321,7 @@ __global__ void __launch_bounds__(256, 2) gemm_chain_kernel(const ChainArgs p) {
       // (the first tile has only the prologue's two younger weight steps behind taps 0..2)
       if constexpr (k < LOOK) { if (first) chain_wait_vm<(LOOK - 1) * B1_INSTR>(); else chain_wait_vm<Ops::wait_for(k)>(); }
       else chain_wait_vm<Ops::wait_for(k)>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
+      tfimm_lds_reuse_barrier();       // (this wave's reads of the stage about to be refilled are complete: common.h)
       if constexpr (DS && k == NK1 - 2) { load_bias1(); __builtin_amdgcn_sched_barrier(0); }
       if constexpr (k == NK1 - 1) {
         load_epi(ChainIdx<0>{});
@@ -394,8 +393,7 @@ __global__ void __launch_bounds__(256, 2) gemm_chain_kernel(const ChainArgs p) {
       constexpr int n0 = u * BN2;
       const unsigned out_off0 = (unsigned)(((size_t)em * p.ldc + n0 + e_c8 * 8) * 2);
       chain_wait_vm<Ops::wait_for(NK1 + u)>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
+      tfimm_lds_reuse_barrier();       // (this wave's reads of the stage about to be refilled are complete: common.h)
       if constexpr (u + 1 < NS2) load_epi(ChainIdx<u + 1>{});
       u32x4 wds[TN2][4];
       if constexpr (DS) {

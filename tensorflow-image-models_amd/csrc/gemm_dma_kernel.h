@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_dma_kernel(const G
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt have landed
-    __builtin_amdgcn_s_barrier();                      // ... everyone's; and stage cur^1 is free again
+    tfimm_lds_reuse_barrier();                         // ... everyone's; and stage cur^1 is free again
     asm volatile("" ::: "memory");
     if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
 

@@ -279,8 +279,7 @@ __global__ void __launch_bounds__(256, 2) gemm_duo_kernel(const GemmStreamArgs p
       } else {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
       }
-      __builtin_amdgcn_s_barrier();                // ... everyone's; the stage of k-tile cur-1 (and the epilogue
-      asm volatile("" ::: "memory");               //     staging in it, and the tables) are free again
+      tfimm_lds_reuse_barrier();                   // ... everyone's; the stage of k-tile cur-1 (and the epilogue block in it) is free: every wave's reads of it are complete
       // first residual rows of this tile: requested ahead of the DMA below, so waiting for them leaves that DMA in flight
       if (!FAST && kt == nk - 1) {
 #pragma unroll

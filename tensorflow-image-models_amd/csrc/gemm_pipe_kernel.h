@@ -215,8 +215,7 @@ __global__ void __launch_bounds__(512) gemm_pipe_kernel(const GemmStreamArgs pa)
       } else {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
       }
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
+      tfimm_lds_reuse_barrier();
       issue_next((cur + 3) & (NS - 1));        // refills the buffer of k-tile cur-1: dead behind this barrier
       // the scheduling barriers pin the software pipeline: hipcc otherwise sinks each fragment read
       // below the MFMAs of the other set (fewer live registers) and the LDS latency is exposed again

@@ -415,8 +415,8 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       stores_pending = false;
-      __builtin_amdgcn_s_barrier();                      // ... everyone's; stage cur^1 (and an aliased
-      asm volatile("" ::: "memory");                     //     epilogue block in it) is free again
+      tfimm_lds_reuse_barrier();                         // ... everyone's; stage cur^1 (and an aliased epilogue block in it) is
+                                                         //     free again: every wave's reads of it are COMPLETE (common.h)
       // first residual rows of THIS tile: requested ahead of the next step's DMA, so the wait for
       // them in the epilogue leaves that DMA in flight
       if (VEC && last && !fast_epi) {

@@ -384,11 +384,7 @@ __global__ void __launch_bounds__(512) mlp_fused_kernel(const MlpArgs p) {
     }
   };
 #define MLP_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
-#define MLP_BARRIER()                 \
-  do {                                \
-    __builtin_amdgcn_s_barrier();     \
-    asm volatile("" ::: "memory");    \
-  } while (0)
+#define MLP_BARRIER() tfimm_lds_reuse_barrier()    /* with this wave's LDS reads complete (common.h) */
 
   // ---- prologue: tables (waves 0-2 one piece each: b1 = 2 pieces, b2 = the valid half of a third), first x tile, W1(0)
   if (wave < 3) {

@@ -96,7 +96,7 @@ def test_truncated_and_corrupted_blobs_are_refused_not_followed(name):
     ws = torch.empty(int(info.workspace_bytes), dtype=torch.uint8, device="cuda")
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     refused = created = 0
-    for pos in rng.integers(28, head, size=120):
+    for pos in rng.integers(28, head, size=40):
         pos = int(pos) & ~3
         for word in (b"\xff\xff\xff\xff", b"\xff\xff\xff\x7f", b"\x00\x00\x00\x80"):
             bad = blob[:pos] + word + blob[pos + 4:]

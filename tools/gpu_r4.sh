@@ -39,7 +39,7 @@ for k, v in d["also"].items():
 PY
       ;;
     tests)
-      timeout 3000 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; echo "tests rc=$?"; tail -n 5 $O/pytest_gpu.txt ;;
+      timeout 3000 python -m pytest tests -m gpu -x -q --durations=12 > $O/pytest_gpu.txt 2>&1; echo "tests rc=$?"; tail -n 5 $O/pytest_gpu.txt ;;
     cait)
       TFIMM_BRANCHES=2 timeout 1500 python -m pytest tests/test_gpu_models.py tests/test_gpu_branches.py -m gpu -q -k "cait" > $O/cait_branches.txt 2>&1; tail -n 4 $O/cait_branches.txt
       timeout 600 python tools/branch_hunt.py cait_xxs24_224 64 12 > $O/branch_hunt.txt 2>&1; tail -n 6 $O/branch_hunt.txt
