@@ -119,6 +119,12 @@ PY
       done
       bash tools/gpu_traffic.sh > $O/traffic.log 2>&1; tail -14 $O/traffic.log; cp gpurun_out/traffic.json $O/traffic.json
       rm -rf gpurun_out/traffic_* ;;
+    repro)
+      # every op output of the scored workloads (and a few others) bit-equal over eager launches and graph replays
+      for m in "resnet50 256" "vit_base_patch16_224 512" "swin_base_patch4_window7_224 256" "efficientnet_b4 256" "convnext_base 128" \
+               "seresnet50 64" "cait_xxs24_224 64" "efficientnet_b0 64" "mobilenet_v2_100 64" "resnet50 128" "vit_base_patch16_224 256"; do
+        timeout 400 python tools/flaky_hunt.py $m 10 3 2>/dev/null | tail -1
+      done > $O/reproducibility.txt; cat $O/reproducibility.txt ;;
     plancapi)
       timeout 900 python -m pytest tests/test_gpu_plan_capi.py -x -q > $O/plancapi.txt 2>&1; tail -n 5 $O/plancapi.txt ;;
     memset)
