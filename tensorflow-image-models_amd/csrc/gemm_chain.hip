@@ -20,6 +20,9 @@ int chain_num_cu() {
 }
 }  // namespace
 
+// csrc/conv_strip.hip
+int tfimm_launch_conv_strip_chain(const tfimm_chain_desc& d, int64_t M, int num_cu, hipStream_t stream);
+
 extern "C" int tfimm_hip_conv_chain(const tfimm_chain_desc* dp, void* stream) {
   if (!dp) TFIMM_FAIL(TFIMM_EINVAL, "conv_chain: null descriptor");
   const tfimm_chain_desc& d = *dp;
@@ -27,6 +30,38 @@ extern "C" int tfimm_hip_conv_chain(const tfimm_chain_desc* dp, void* stream) {
   if (d.B <= 0 || d.H <= 0 || d.W <= 0 || d.Cin <= 0 || d.KH <= 0 || d.KW <= 0 || d.stride <= 0 || d.OH <= 0 || d.OW <= 0 ||
       d.C1 <= 0 || d.N2 <= 0)
     TFIMM_FAIL(TFIMM_EINVAL, "conv_chain: bad shape");
+  // C1 = 128 (ResNet stage 2): the input-strip kernel with the 1x1 convolution chained behind it (csrc/conv_strip.hip)
+  if (d.C1 == 128) {
+    if (d.Cin != 128 || d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad_t != 1 || d.pad_l != 1 || d.OH != d.H || d.OW != d.W)
+      TFIMM_FAIL(TFIMM_EUNSUP, "conv_chain: C1 = 128 is built for a 3x3 / stride 1 / pad 1 convolution over 128 -> 128 channels");
+    if (d.W > 31) TFIMM_FAIL(TFIMM_EUNSUP, "conv_chain: C1 = 128 needs W <= 31 (W = %d): the strip of a 128-pixel tile must fit 192 LDS rows", d.W);
+    if (d.N2 != 256 && d.N2 != 512) TFIMM_FAIL(TFIMM_EUNSUP, "conv_chain: N2 = %d (built: 256, 512)", d.N2);
+    if (d.ds_x || d.ds_w) TFIMM_FAIL(TFIMM_EUNSUP, "conv_chain: the shortcut-convolution flavour exists for C1 = 64 only");
+    if (d.ldw1 != 1152) TFIMM_FAIL(TFIMM_EINVAL, "conv_chain: ldw1 = %d, expected KH*KW*Cin = 1152", d.ldw1);
+    if (d.ldw2 < 128 || (d.ldw2 & 7)) TFIMM_FAIL(TFIMM_EINVAL, "conv_chain: ldw2 = %d", d.ldw2);
+    if (d.ldc < d.N2 || (d.ldc & 7) || (d.residual && (d.ldr < d.N2 || (d.ldr & 7))))
+      TFIMM_FAIL(TFIMM_EINVAL, "conv_chain: output / residual rows must be 16-byte aligned (ldc = %d, ldr = %d)", d.ldc, d.ldr);
+    if (((uintptr_t)d.x | (uintptr_t)d.w1 | (uintptr_t)d.w2 | (uintptr_t)d.out | (uintptr_t)d.residual | (uintptr_t)d.b1 | (uintptr_t)d.b2) & 15)
+      TFIMM_FAIL(TFIMM_EINVAL, "conv_chain: pointers must be 16-byte aligned");
+    const int64_t M = (int64_t)d.B * d.OH * d.OW;
+    const int64_t big = std::max<int64_t>(M * 256, ((M - 1) * std::max(d.ldc, d.ldr) + d.N2) * 2);
+    if (big > 0x7fffff00LL) {       // image chunks, as below
+      const int64_t per_img = (int64_t)d.OH * d.OW * std::max<int64_t>(256, (int64_t)std::max(d.ldc, d.ldr) * 2);
+      const int64_t chunk = 0x7fffff00LL / per_img;
+      if (chunk < 1 || d.B <= 1) TFIMM_FAIL(TFIMM_EUNSUP, "conv_chain: one image exceeds the 2 GiB a buffer descriptor addresses");
+      for (int64_t b0 = 0; b0 < d.B; b0 += chunk) {
+        tfimm_chain_desc c = d;
+        c.B = (int32_t)std::min<int64_t>(chunk, d.B - b0);
+        c.x = (const char*)d.x + b0 * d.H * d.W * 256;
+        c.out = (char*)d.out + b0 * d.OH * d.OW * d.ldc * 2;
+        if (d.residual) c.residual = (const char*)d.residual + b0 * d.OH * d.OW * d.ldr * 2;
+        const int rc = tfimm_hip_conv_chain(&c, stream);
+        if (rc != 0) return rc;
+      }
+      return 0;
+    }
+    return tfimm_launch_conv_strip_chain(d, M, chain_num_cu(), (hipStream_t)stream);
+  }
   // built: 3x3 / stride 1 / pad 1 over 64 -> 64 channels (input strip: W <= 63), 256 or 512 output channels
   if (d.C1 != 64 || d.Cin != 64 || d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad_t != 1 || d.pad_l != 1 || d.OH != d.H ||
       d.OW != d.W)

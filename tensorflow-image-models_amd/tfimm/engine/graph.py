@@ -407,7 +407,11 @@ class Builder:
         kh, kw, cin, c1 = k1.shape
         n2 = k2.shape[3]
         # what tfimm_hip_conv_chain is built for: 3x3 / stride 1 / pad 1 over 64 -> 64 channels, rows of at most 63 pixels
-        if (x.C != cin or (kh, kw, cin, c1) != (3, 3, 64, 64) or stride != 1 or int(padding) != 1 or x.W > 63
+        # (gemm_chain_kernel.h), or over 128 -> 128 channels, rows of at most 31 pixels (conv_strip.hip; no shortcut convolution)
+        shape_ok = ((kh, kw, cin, c1) == (3, 3, 64, 64) and x.W <= 63) or \
+                   ((kh, kw, cin, c1) == (3, 3, 128, 128) and x.W <= 31 and shortcut_conv is None
+                    and os.environ.get("TFIMM_NO_CHAIN128", "0") != "1")
+        if (x.C != cin or not shape_ok or stride != 1 or int(padding) != 1
                 or n2 not in (256, 512) or k2.shape[:3] != (1, 1, c1) or os.environ.get("TFIMM_NO_CHAIN", "0") == "1"
                 or self.fp32):
             return None

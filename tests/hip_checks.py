@@ -1224,6 +1224,13 @@ CASES["chain_multiround_b40"] = lambda: _chain_case(40, 56, 56, 64, 256, 1, 185)
 CASES["chain_multiround_b130_28x28"] = lambda: _chain_case(130, 28, 28, 64, 256, 1, 186)       # 399 tiles, images smaller than a tile... of 256 pixels
 CASES["chain_n512"] = lambda: _chain_case(3, 14, 14, 64, 512, 1, 187)                          # four GEMM-2 steps
 CASES["chain_single_image_1x1"] = lambda: _chain_case(3, 1, 1, 64, 256, 1, 188)                # every tap but the centre masked
+# C1 = 128 (ResNet stage 2): the input-strip kernel with the 1x1 convolution chained behind it (csrc/conv_strip.hip)
+CASES["chain128_28x28_b6"] = lambda: _chain_case(6, 28, 28, 128, 512, 1, 420)                  # 37 tiles, the last one ragged
+CASES["chain128_odd_17x23"] = lambda: _chain_case(3, 17, 23, 128, 512, 1, 421)
+CASES["chain128_31_wide_n256"] = lambda: _chain_case(2, 9, 31, 128, 256, 1, 422)               # widest row; four GEMM-2 slices
+CASES["chain128_no_residual_tiny"] = lambda: _chain_case(1, 5, 7, 128, 512, 1, 423, residual=False)
+CASES["chain128_multiround_b130"] = lambda: _chain_case(130, 28, 28, 128, 512, 1, 424)         # 797 tiles: two per workgroup
+CASES["chain128_1x1_images"] = lambda: _chain_case(150, 1, 1, 128, 512, 1, 425)
 
 
 def _chain_ds_case(B, Hh, Ww, N2, seed):
@@ -1360,6 +1367,7 @@ CASES["tight_vit_b_proj_residual"] = _tight(lambda: _gemm_case(2048, 768, 768, r
 CASES["tight_resnet50_chain_stage1"] = _tight(lambda: _chain_case(6, 56, 56, 64, 256, 1, 904), stages=2)
 CASES["tight_resnet50_chain_stage1_shortcut_conv"] = _tight(lambda: _chain_ds_case(6, 56, 56, 256, 905), stages=2)
 CASES["tight_resnet50_stem_conv_pool"] = _tight(lambda: _stem_pool_case(3, 224, 224, 906), stages=2)
+CASES["tight_resnet50_chain_stage2"] = _tight(lambda: _chain_case(6, 28, 28, 128, 512, 1, 919), stages=2)
 CASES["tight_resnet50_conv1_relu"] = _tight(lambda: _gemm_case(6 * 3136, 256, 64, act="relu", seed=907))
 CASES["tight_resnet50_conv3_residual_relu"] = _tight(lambda: _gemm_case(6 * 784, 128, 512, act="relu", residual=True, act_after_res=True, seed=908))
 CASES["tight_resnet50_conv3x3_stage2"] = _tight(lambda: _conv_case(6, 28, 28, 128, 128, 3, 1, 1, act="relu", seed=909))

@@ -118,8 +118,11 @@ def test_resnet50_stage1_tails_are_one_launch_each():
     """conv2 + bn2 + relu + conv3 + bn3 + shortcut + relu of the three stage-1 blocks lower to tfimm_hip_conv_chain (the
     64-channel intermediate never reaches HBM); the algorithmic FLOP count is unchanged; TFIMM_NO_CHAIN=1 keeps two GEMMs"""
     kinds, prog = _kinds("resnet50")
-    chains = [op for op in prog.ops if op.kind == "conv_chain"]
+    chains = [op for op in prog.ops if op.kind == "conv_chain" and op.attrs["C1"] == 64]
     assert len(chains) == 3 and all((op.attrs["H"], op.attrs["C1"], op.attrs["N2"]) == (56, 64, 256) for op in chains)
+    # ... and so do the three stride-1 blocks of stage 2 (128 -> 128 -> 512 at 28 x 28: csrc/conv_strip.hip, round 4)
+    chains2 = [op for op in prog.ops if op.kind == "conv_chain" and op.attrs["C1"] == 128]
+    assert [(op.attrs["H"], op.attrs["N2"], op.attrs["has_residual"], bool(op.attrs.get("has_ds"))) for op in chains2] == [(28, 512, True, False)] * 3
     # the first block's shortcut convolution (64 -> 256 on the stem output) is multiplied inside its tail: no launch, no tensor
     assert [(op.attrs["has_residual"], bool(op.attrs.get("has_ds"))) for op in chains] == [(False, True), (True, False), (True, False)]
     assert not [op for op in prog.ops if op.kind == "gemm" and op.attrs.get("K") == 64 and op.attrs["N"] == 256]

@@ -125,6 +125,55 @@ PY
                "seresnet50 64" "cait_xxs24_224 64" "efficientnet_b0 64" "mobilenet_v2_100 64" "resnet50 128" "vit_base_patch16_224 256"; do
         timeout 400 python tools/flaky_hunt.py $m 10 3 2>/dev/null | tail -1
       done > $O/reproducibility.txt; cat $O/reproducibility.txt ;;
+    chain128)
+      timeout 900 python - > $O/chain128.txt 2>&1 <<PY
+import sys, time
+sys.path[:0] = ["$R", "$R/tensorflow-image-models_amd", "$R/tests"]
+import numpy as np, torch
+import hip_checks, hip_ops as H
+from tfimm.engine import pack
+import os
+for n in sorted(hip_checks.CASES):
+    if os.environ.get("SKIP_CASES"): break
+    if "chain128" in n or n == "tight_resnet50_chain_stage2":
+        try:
+            e, tol = hip_checks.run_case(n)
+            print(f"{n:44s} {e:10.3e} of {tol:.1e}", flush=True)
+        except Exception as ex:
+            print(f"{n:44s} FAILED {type(ex).__name__}: {ex}", flush=True)
+# timing at the scored shape: stage-2 tail of ResNet-50, batch 256 / 128
+r = np.random.default_rng(0)
+C, N2 = 128, 512
+k1 = (r.standard_normal((3, 3, C, C)) / 34).astype(np.float32)
+k2 = (r.standard_normal((C, N2)) / 11).astype(np.float32)
+wt1, b1, K1, mode = pack.pack_conv(k1, np.ones(C, np.float32), np.zeros(C, np.float32), C)
+wt2, b2 = pack.pack_dense(k2[pack.chain_k_order(C)], np.zeros(N2, np.float32))
+wt2p, _ = pack.pack_dense(k2, None)
+w1d, b1d, w2d, b2d, w2pd = H.dev_bits(wt1), H.dev_f32(b1), H.dev_bits(wt2), H.dev_f32(b2), H.dev_bits(wt2p)
+for B in (256, 128):
+    M = B * 784
+    x = torch.randn(B, 28, 28, C, device="cuda").to(torch.bfloat16)
+    res = torch.randn(M, N2, device="cuda").to(torch.bfloat16)
+    conv = dict(mode=mode, B=B, H=28, W=28, Cin=C, KH=3, KW=3, stride=1, pad_t=1, pad_l=1, OH=28, OW=28)
+    def fused():
+        return H.conv_chain(x, w1d, b1d, w2d, b2d, res, KH=3, KW=3, stride=1, pad=1, OH=28, OW=28, C1=C, N2=N2)
+    mid = torch.empty(M, C, dtype=torch.bfloat16, device="cuda"); out = torch.empty(M, N2, dtype=torch.bfloat16, device="cuda")
+    def two():
+        H.gemm(x, w1d, C, K1, bias=b1d, act="relu", conv=conv, tile_hint=31, out=mid)
+        return H.gemm(mid, w2pd, N2, C, bias=b2d, residual=res, act="relu", act_after_res=True, out=out)
+    for name, fn in (("fused", fused), ("strip + 1x1", two)):
+        try:
+            for _ in range(3): fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20): fn()
+            e1.record(); torch.cuda.synchronize()
+            print(f"B={B} {name:12s} {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us", flush=True)
+        except Exception as ex:
+            print(f"B={B} {name} FAILED {type(ex).__name__}: {ex}", flush=True)
+PY
+      grep -v amdgpu.ids $O/chain128.txt ;;
     plancapi)
       timeout 900 python -m pytest tests/test_gpu_plan_capi.py -x -q > $O/plancapi.txt 2>&1; tail -n 5 $O/plancapi.txt ;;
     memset)
