@@ -1459,6 +1459,7 @@ class Plan:
             # the fused ResNet stem can read the caller's image itself: exported pointing at the converted copy, the executor
             # re-points it per forward (tfimm_hip_plan_forward)
             stem_desc, padded_ptr, _, _, pad_t, pad_l = self._stem_raw
+            stem_live = (stem_desc.x, stem_desc.in_dtype)          # the live plan keeps its own setting: restored below
             stem_desc.x, stem_desc.in_dtype = padded_ptr, 0
             stem_call = next(i for i, (fn, a) in enumerate(self.calls) if a and getattr(a[0], "_obj", None) is stem_desc)
         calls = []
@@ -1476,6 +1477,8 @@ class Plan:
             calls.append((fn.__name__, refs))
         stem_struct = struct_ids[id(stem_desc)] if stem_desc is not None else -1
         stem_call = -1 if stem_call is None else stem_call
+        if stem_desc is not None:
+            stem_desc.x, stem_desc.in_dtype = stem_live            # (every struct has been serialised by now)
         H, W, cin = self.prog.input_shape
 
         def build(const_offsets, host_offsets):
