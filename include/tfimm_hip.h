@@ -365,7 +365,8 @@ TFIMM_API int tfimm_hip_patch_merge_ln(const void* x, void* y, const float* gamm
  * quads are swapped (k-slot 16t + s holds channel 16t + {0..3, 8..11, 4..7, 12..15}[s]) -- the order in which a wave's
  * GEMM-1 accumulators become the register operand of GEMM 2 (tfimm/engine/pack.py chain_k_order); residual (may be
  * NULL) / out: bf16 rows of ldr / ldc elements (multiples of 8); M = B*OH*OW.  Built for the ResNet stage-1 shape --
- * 3x3 / stride 1 / pad 1, Cin = C1 = 64, W <= 63, N2 in {256, 512}; anything else returns TFIMM_EUNSUP and the caller
+ * 3x3 / stride 1 / pad 1, Cin = C1 = 64, W <= 63, N2 in {256, 512} (csrc/gemm_chain_kernel.h) -- and the stage-2 shape --
+ * Cin = C1 = 128, W <= 31, N2 in {256, 512}, no shortcut convolution (csrc/conv_strip.hip); anything else returns TFIMM_EUNSUP and the caller
  * runs the two convolutions as two tfimm_hip_gemm launches (same arithmetic: fp32 accumulation, the intermediate
  * rounded to bf16 once; only the summation order inside GEMM 2's 16-wide k-steps differs).
  * ------------------------------------------------------------------------------------- */
