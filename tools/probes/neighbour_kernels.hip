@@ -179,8 +179,14 @@ __global__ void __launch_bounds__(256) ldsret_victim_kernel(unsigned* counts, in
       LDSRET_READ("v_pk_fma_f32 %1, %4, %4, %0 op_sel:[0,0,1]")
       e0 = e1 = (float)(1000 + lane);
     } else if (FORM == 8) {
-      LDSRET_READ("v_pk_mov_b32 %1, %0, %0 op_sel:[1,0]")
-      e0 = (float)(1000 + lane); e1 = (float)(1000 + lane);
+      LDSRET_READ("v_pk_mov_b32 %1, %0, %0 op_sel:[1,0]")        // D.lo = src0.hi, D.hi = src1.lo
+      e0 = (float)(1000 + lane); e1 = (float)(lane + 1);
+    } else if (FORM == 9) {
+      LDSRET_READ("v_pk_mul_f32 %1, %3, %0 op_sel:[0,1]")          // src1 high -> low
+      e0 = e1 = (float)(1000 + lane);
+    } else if (FORM == 10) {
+      LDSRET_READ("v_pk_add_f32 %1, %4, %0 op_sel:[0,1]")          // src1 high -> low
+      e0 = e1 = (float)(1000 + lane);
     } else if (FORM == 7) {
       // no LDS at all: the pair comes out of VALU instructions
       r = f2{(float)(lane + 1), (float)(1000 + lane)};
@@ -213,7 +219,7 @@ extern "C" int ldsret_victim_launch(unsigned* counts, int iters, int form, int n
   void (*fn)(unsigned*, int) = nullptr;
 #define PICK(F, N, R) if (form == F && nops == N && read == R) fn = ldsret_victim_kernel<F, N, R>;
 #define PICKN(F, R) PICK(F, 0, R) PICK(F, 1, R) PICK(F, 2, R) PICK(F, 4, R) PICK(F, 8, R)
-  PICKN(0, 0) PICKN(1, 0) PICKN(2, 0) PICKN(3, 0) PICKN(4, 0) PICKN(5, 0) PICKN(6, 0) PICKN(7, 0) PICKN(8, 0) PICKN(0, 1) PICKN(1, 1) PICKN(2, 1)
+  PICKN(0, 0) PICKN(1, 0) PICKN(2, 0) PICKN(3, 0) PICKN(4, 0) PICKN(5, 0) PICKN(6, 0) PICKN(7, 0) PICKN(8, 0) PICKN(9, 0) PICKN(10, 0) PICKN(0, 1) PICKN(1, 1) PICKN(2, 1)
   if (!fn) return -2;
   if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
   hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, counts, iters);

@@ -164,9 +164,10 @@ if "ldsret" in WHICH:
     FORMS = {0: "v_pk_add_f32 (no operand select)", 1: "v_pk_fma_f32 op_sel:[0,1,0] (src1 high -> low)", 2: "v_pk_fma_f32 op_sel_hi:[1,0,0] (src1 low -> high)",
              3: "address register overwritten behind the read", 4: "v_pk_mul_f32 op_sel:[1,0] (src0 high -> low)",
              5: "v_pk_fma_f32 op_sel:[1,0,0] (src0 high -> low)", 6: "v_pk_fma_f32 op_sel:[0,0,1] (src2 high -> low)",
-             7: "v_pk_fma_f32 op_sel:[0,1,0], pair from VALU (no LDS)", 8: "v_pk_mov_b32 op_sel:[1,0] (src0 high -> low)"}
+             7: "v_pk_fma_f32 op_sel:[0,1,0], pair from VALU (no LDS)", 8: "v_pk_mov_b32 op_sel:[1,0] (src0 high -> low)",
+             9: "v_pk_mul_f32 op_sel:[0,1] (src1 high -> low)", 10: "v_pk_add_f32 op_sel:[0,1] (src1 high -> low)"}
     for name, nb in CASES:
-        for form, read, nops in [(f, rd, n) for f in (0, 1, 2, 4, 5, 6, 7, 8) for rd in (0,) for n in (0, 8)]:
+        for form, read, nops in [(f, rd, n) for f in ((8, 9, 10, 1) if os.environ.get('FORMS') == 'more' else (0, 1, 2, 4, 5, 6, 7, 8)) for rd in (0,) for n in (0,)]:
             counts.zero_()
             if nb is not None:
                 nb()
