@@ -1,4 +1,5 @@
-"""Dump s_memtime stamps of workgroup 0 of the persistent GEMM: pp_stamps.py M K N"""
+"""NEEDS A PROBE BUILD: the *_DBG switches / stamps exist only with -DTFIMM_PROBE_HOOKS (tools/probes/build_dbg_libs.sh all; TFIMM_HIP_LIB=tools/probes/bin/libtfimm_hip_probe.so).
+Dump s_memtime stamps of workgroup 0 of the persistent GEMM: pp_stamps.py M K N"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tensorflow-image-models_amd"), os.path.join(ROOT, "tests")):

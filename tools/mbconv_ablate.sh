@@ -1,4 +1,5 @@
 #!/bin/bash
+# NEEDS A PROBE BUILD: the *_DBG switches exist only with -DTFIMM_PROBE_HOOKS (tools/probes/build_dbg_libs.sh all; export TFIMM_HIP_LIB=tools/probes/bin/libtfimm_hip_probe.so)
 # fused MBConv front: per-op time on the EfficientNet-B4 shapes under the TFIMM_MB_DBG ablation switches
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd $R

@@ -1,4 +1,5 @@
-"""Time the ResNet stem (7x7 s2 RGB conv on the pixel-pair view) per tile hint, optional cycle stamps of workgroup 0:
+"""NEEDS A PROBE BUILD: the *_DBG switches / stamps exist only with -DTFIMM_PROBE_HOOKS (tools/probes/build_dbg_libs.sh all; TFIMM_HIP_LIB=tools/probes/bin/libtfimm_hip_probe.so).
+Time the ResNet stem (7x7 s2 RGB conv on the pixel-pair view) per tile hint, optional cycle stamps of workgroup 0:
    stem_probe.py [B] [hints comma-separated] [stamps 0/1]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
