@@ -193,7 +193,11 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
               const int q = 2 * h + (e >> 1), r = (e & 1) * 2;
               v[e] = tfimm_f32x2{acc[q * 4 + r] + bq[q][r], acc[q * 4 + r + 1] + bq[q][r + 1]};
             }
-            if (!(TFIMM_PROBE(p.dbg) & 4)) act8p(v, a1);
+            // p.dbg is a RUN-TIME zero in product builds (the host passes 0 unless built with -DTFIMM_PROBE_HOOKS), on purpose:
+            // with the three switches of this kernel folded away at compile time hipcc allocates 14-48 registers more than the
+            // 128 the launch bounds give it and spills them (expand_dw 3.8 -> 4.9 ms per EfficientNet-B4 forward, round 4);
+            // scheduling barriers in their place do not bring the old allocation back, the branches do
+            if (!(p.dbg & 4)) act8p(v, a1);
             if (px < G::NPX) {
 #pragma unroll
               for (int qq = 0; qq < 2; ++qq) {
@@ -255,13 +259,13 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
         tfimm_f32x2 v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (r0 + e < RPTL) ? acc[(r0 + e < RPTL) ? r0 + e : 0] : tfimm_f32x2{0.f, 0.f};
-        if (!(TFIMM_PROBE(p.dbg) & 2)) act8p(v, a2);
+        if (!(p.dbg & 2)) act8p(v, a2);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (r0 + e < RPTL) {
             const uint32_t pk = pack_bf2(v[e][0], v[e][1]);
             if (cok && oybl + r0 + e < p.OH) {
-              if (!(TFIMM_PROBE(p.dbg) & 1)) *reinterpret_cast<uint32_t*>(yb + (size_t)(r0 + e) * p.OW * p.C) = pk;
+              if (!(p.dbg & 1)) *reinterpret_cast<uint32_t*>(yb + (size_t)(r0 + e) * p.OW * p.C) = pk;
               // the squeeze sees the stored (bf16-rounded) activations, as in tfimm_hip_dwconv
               tot += tfimm_f32x2{__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)};
             }
@@ -337,8 +341,12 @@ extern "C" int tfimm_hip_expand_dwconv(const tfimm_expand_dw_desc* d, void* stre
   a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.C = d->C; a.Cpad = d->Cpad; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
   a.OH = d->OH; a.OW = d->OW; a.tiles_x = 0; a.act1 = d->act1; a.act2 = d->act2;
   a.img_h = d->img_h; a.img_w = d->img_w;
-  static const int dbg = getenv("TFIMM_MB_DBG") ? atoi(getenv("TFIMM_MB_DBG")) : 0;
+#ifdef TFIMM_PROBE_HOOKS
+  static const int dbg = getenv("TFIMM_MB_DBG") ? atoi(getenv("TFIMM_MB_DBG")) : 0;     // ablation switches: probe builds only
   a.dbg = dbg;
+#else
+  a.dbg = 0;            // (a run-time zero the kernel still branches on: see the comment there)
+#endif
   hipStream_t st = (hipStream_t)stream;
   if (d->stem) {
     if (a.act1 == a.act2 && a.act1 == TFIMM_ACT_SWISH) return launch_expand_dw_act<3, 1, 12, 32, TFIMM_ACT_SWISH, true>(a, d->B, st);
