@@ -102,22 +102,23 @@ PY
     profiles)
       # the round's evidence from ONE box: rocprofv3 kernel stats + per-op profiles + MFMA-busy / wave-state PMC passes of the four
       # scored workloads, the HBM-traffic PMC passes; summaries under gpurun_out/r4/ (copy to profiles/r04_*)
+      WLS=${WL:-resnet50 vit_base_patch16_224 swin_base_patch4_window7_224 efficientnet_b4}
       cd /tmp
-      for m in resnet50 vit_base_patch16_224 swin_base_patch4_window7_224 efficientnet_b4; do
+      for m in $WLS; do
         rm -rf $O/prof_$m
         timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$m -o $m -- python $R/bench.py --workload $m --steps 5 --warmup 2 --no-graph --no-cpu-baseline --no-kernel-events --extra "" > $O/prof_$m.log 2>&1; echo "rocprof $m rc=$?"
         f=$(find $O/prof_$m -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${m}_kernel_stats.csv && head -4 $O/${m}_kernel_stats.csv | cut -c1-170
         rm -rf $O/prof_$m
       done
       cd $R
-      for m in resnet50 vit_base_patch16_224 swin_base_patch4_window7_224 efficientnet_b4; do
+      for m in $WLS; do
         timeout 300 python tools/op_profile.py $m > $O/opprof_$m.log 2>&1; echo "opprof $m rc=$?"; cp gpurun_out/opprof_$m.txt $O/ 2>/dev/null; head -1 $O/opprof_$m.txt
       done
-      for m in resnet50 vit_base_patch16_224 swin_base_patch4_window7_224 efficientnet_b4; do
+      for m in $WLS; do
         bash tools/gpu_mfma_busy.sh $m > /dev/null 2>&1; cp gpurun_out/mfma_busy_$m.txt $O/ 2>/dev/null; head -6 $O/mfma_busy_$m.txt | cut -c1-170
         bash tools/gpu_pipe_busy.sh $m > /dev/null 2>&1; cp gpurun_out/pipe_busy_$m.txt $O/ 2>/dev/null
       done
-      bash tools/gpu_traffic.sh > $O/traffic.log 2>&1; tail -14 $O/traffic.log; cp gpurun_out/traffic.json $O/traffic.json
+      bash tools/gpu_traffic.sh $WLS > $O/traffic.log 2>&1; tail -14 $O/traffic.log; cp gpurun_out/traffic.json $O/traffic_${WL:+partial_}all.json
       rm -rf gpurun_out/traffic_* ;;
     repro)
       # every op output of the scored workloads (and a few others) bit-equal over eager launches and graph replays
