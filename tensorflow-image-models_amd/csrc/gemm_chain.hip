@@ -45,9 +45,11 @@ extern "C" int tfimm_hip_conv_chain(const tfimm_chain_desc* dp, void* stream) {
       TFIMM_FAIL(TFIMM_EINVAL, "conv_chain: pointers must be 16-byte aligned");
     const int64_t M = (int64_t)d.B * d.OH * d.OW;
     const int64_t big = std::max<int64_t>(M * 256, ((M - 1) * std::max(d.ldc, d.ldr) + d.N2) * 2);
-    if (big > 0x7fffff00LL) {       // image chunks, as below
+    // (TFIMM_CHAIN_LIMIT lowers the threshold, as for C1 = 64 below: lets a test exercise the chunking on a small batch)
+    static const int64_t lim128 = getenv("TFIMM_CHAIN_LIMIT") ? std::min<int64_t>(atoll(getenv("TFIMM_CHAIN_LIMIT")), 0x7fffff00LL) : 0x7fffff00LL;
+    if (big > lim128) {             // image chunks, as below
       const int64_t per_img = (int64_t)d.OH * d.OW * std::max<int64_t>(256, (int64_t)std::max(d.ldc, d.ldr) * 2);
-      const int64_t chunk = 0x7fffff00LL / per_img;
+      const int64_t chunk = lim128 / per_img;
       if (chunk < 1 || d.B <= 1) TFIMM_FAIL(TFIMM_EUNSUP, "conv_chain: one image exceeds the 2 GiB a buffer descriptor addresses");
       for (int64_t b0 = 0; b0 < d.B; b0 += chunk) {
         tfimm_chain_desc c = d;
