@@ -380,10 +380,15 @@ def roofline_of(name, wl, r, steps, batch):
     second = None
     if wl.get("second_bound") == "mfma":
         tf_s = sum(k["flops"] for k in fam) / (fam_ms * 1e-3) / 1e12
+        n_fused = sum(1 for op in prog.ops if op.kind == "mlp_fused")
+        n_split = sum(1 for op in prog.ops if op.kind == "gemm" and op.attrs.get("act") == "gelu")
         second = dict(bound="mfma", achieved=round(tf_s, 2), peak=PEAK["mfma"][0], unit=PEAK["mfma"][1],
                       frac=round(tf_s / PEAK["mfma"][0], 4),
+                      mlp_blocks_in_one_kernel=f"{n_fused} of {n_fused + n_split}",
                       note="the same family's FLOPs over the same time against the dense bf16 MFMA peak: the bound that "
-                           "applies once the MLP (fc1 -> GELU -> fc2) is a single kernel (SURVEY.md 8d)")
+                           "applies once the MLP (fc1 -> GELU -> fc2) is a single kernel (SURVEY.md 8d); today only the "
+                           "128-channel stage runs it as one launch (mlp_blocks_in_one_kernel), the others write and re-read "
+                           "the hidden tensor, so the HBM bound above is the one that applies to them")
     return dict(bound=bound, achieved=round(achieved, 2), peak=peak, unit=punit, frac=round(achieved / peak, 4),
                 second_bound=second,
                 traffic=traffic, traffic_unit="HBM bytes per launch (PMC)", traffic_source=traffic_src,
