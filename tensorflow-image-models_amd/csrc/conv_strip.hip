@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(256, 2) conv_strip_chain_kernel(const StripCha
 
   for (int tile = t_first; tile < t_hi; tile += t_step) {
     const int m0 = tile * STRIP_BM;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the previous tile's last stores (their data came out of the strip area)
+    // (the previous tile's last stores may still be in flight: their data left LDS for registers before they were issued)
     tfimm_lds_reuse_barrier();
     issue_strip(m0);
     issue_step(0);
