@@ -388,7 +388,9 @@ def roofline_of(name, wl, r, steps, batch):
                       note="the same family's FLOPs over the same time against the dense bf16 MFMA peak: the bound that "
                            "applies once the MLP (fc1 -> GELU -> fc2) is a single kernel (SURVEY.md 8d); today only the "
                            "128-channel stage runs it as one launch (mlp_blocks_in_one_kernel), the others write and re-read "
-                           "the hidden tensor, so the HBM bound above is the one that applies to them")
+                           "the hidden tensor, so the HBM bound above is the one that applies to them.  Wider fused MLPs were "
+                           "priced on the measured op times and rejected (profiles/NOTES_r04.md 8: C = 256 would gain 8 us per "
+                           "block, C = 512 is compute-bound as two launches)")
     return dict(bound=bound, achieved=round(achieved, 2), peak=peak, unit=punit, frac=round(achieved / peak, 4),
                 second_bound=second,
                 traffic=traffic, traffic_unit="HBM bytes per launch (PMC)", traffic_source=traffic_src,
