@@ -297,7 +297,7 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
             s_["flops"] += flops
     return dict(seconds=dt, ms_per_step=dt / steps * 1e3, median_ms_per_step=median_ms, gather_bit_equal=gather_bit_equal,
                 forked_bit_equal=forked_bit_equal, kernels=stats, logits=logits, x=x, prog=prog,
-                graph=captured is not None, gathered=gathered, branches=(2 if forked is not None else 1),
+                graph=captured is not None, gathered=gathered, branches=(n_br if forked is not None else 1),
                 hybrid_cut=(hybrid_cut if forked is not None and hybrid_cut is not None and getattr(forked, "cut_op", None) == hybrid_cut else None),
                 n_ops=len(prog.ops),
                 single_branch_ms=single_ms, forked_ms=forked_ms,
@@ -617,7 +617,9 @@ def run_workload(name, args, world, rank, dist, steps, warmup, batch=0, micro_ba
                    forked_bit_equal_to_single=r["forked_bit_equal"], per_gpu_batch=batch,
                    global_batch=total, per_rank_ms=per_rank, model=wl["model"], input_size=int(model.cfg.input_size[0]),
                    launch=("eager" if not r["graph"] else "hipGraph replay" if r["branches"] == 1 else
-                           f"hipGraph replay, {r['branches']} parallel branches of {batch // r['branches']} images" +
+                           f"hipGraph replay, {r['branches']} parallel branches of " +
+                           (f"{batch // r['branches']}" if batch % r['branches'] == 0 else
+                            f"{batch // r['branches']}-{-(-batch // r['branches'])}") + " images" +
                            (f" for ops 0..{r['hybrid_cut'] - 1} of {r['n_ops']}, the full batch for the rest" if r["hybrid_cut"] else "")),
                    branches=r["branches"],
                    single_branch_ms_per_step=None if r["single_branch_ms"] is None else round(r["single_branch_ms"], 4),
