@@ -1528,10 +1528,10 @@ __global__ void fill_bytes_kernel(uint32_t* dst, uint32_t word, size_t n_words) 
 
 extern "C" int tfimm_hip_memset_async(void* dst, int value, size_t bytes, void* stream) {
   if (!dst) TFIMM_FAIL(TFIMM_EINVAL, "memset_async: null pointer");
-  // A fill KERNEL, not hipMemsetAsync: recorded into a HIP graph the latter becomes a memset node, and with those the
-  // squeeze sums of a replayed EfficientNet plan came back as garbage from the fourth replay on in one buffer layout
-  // (tools/flaky_hunt.py, every tensor in its own allocation; bit-exact with this kernel in the same layout, and with
-  // memset nodes in the usual layout -- ROCm 7.2; TFIMM_MEMSET_NODE=1 restores the runtime call for comparison).
+  // A fill KERNEL, not hipMemsetAsync: recorded into a HIP graph the latter becomes a memset node, and such a node writes the
+  // recorded value on the first replay only -- afterwards a 16-byte pattern of host memory (the HIP 7.0 runtime of the PyTorch
+  // wheel; graphs of nothing but memset nodes show it: tools/probes/memset_node_probe.py, profiles/r04_memset_node_probe.txt).
+  // TFIMM_MEMSET_NODE=1 keeps the runtime call reachable for that probe.
   static const bool use_node = getenv("TFIMM_MEMSET_NODE") && atoi(getenv("TFIMM_MEMSET_NODE")) != 0;
   if (!use_node && (bytes & 3) == 0 && (((uintptr_t)dst) & 3) == 0) {
     const uint32_t b = (uint32_t)(value & 0xff), word = b | (b << 8) | (b << 16) | (b << 24);
