@@ -1526,6 +1526,10 @@ __global__ void fill_bytes_kernel(uint32_t* dst, uint32_t word, size_t n_words) 
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) dst[i] = word;
 }
 
+__global__ void fill_odd_bytes_kernel(uint8_t* dst, uint8_t b, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = b;
+}
+
 extern "C" int tfimm_hip_memset_async(void* dst, int value, size_t bytes, void* stream) {
   if (!dst) TFIMM_FAIL(TFIMM_EINVAL, "memset_async: null pointer");
   // A fill KERNEL, not hipMemsetAsync: recorded into a HIP graph the latter becomes a memset node, and such a node writes the
@@ -1533,14 +1537,18 @@ extern "C" int tfimm_hip_memset_async(void* dst, int value, size_t bytes, void* 
   // wheel; graphs of nothing but memset nodes show it: tools/probes/memset_node_probe.py, profiles/r04_memset_node_probe.txt).
   // TFIMM_MEMSET_NODE=1 keeps the runtime call reachable for that probe.
   static const bool use_node = getenv("TFIMM_MEMSET_NODE") && atoi(getenv("TFIMM_MEMSET_NODE")) != 0;
-  if (!use_node && (bytes & 3) == 0 && (((uintptr_t)dst) & 3) == 0) {
-    const uint32_t b = (uint32_t)(value & 0xff), word = b | (b << 8) | (b << 16) | (b << 24);
-    const size_t n = bytes / 4;
-    if (n == 0) return 0;
-    TFIMM_LAUNCH(fill_bytes_kernel, dim3(grid_for((int64_t)n, 256)), dim3(256), 0, (hipStream_t)stream, (uint32_t*)dst, word, n);
+  if (use_node) {
+    TFIMM_HIP_CHECK(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
     return 0;
   }
-  TFIMM_HIP_CHECK(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
+  if (bytes == 0) return 0;
+  const uint32_t b = (uint32_t)(value & 0xff), word = b | (b << 8) | (b << 16) | (b << 24);
+  if ((bytes & 3) == 0 && (((uintptr_t)dst) & 3) == 0) {
+    const size_t n = bytes / 4;
+    TFIMM_LAUNCH(fill_bytes_kernel, dim3(grid_for((int64_t)n, 256)), dim3(256), 0, (hipStream_t)stream, (uint32_t*)dst, word, n);
+  } else {      // odd sizes / addresses: byte by byte (no caller on the model path has them)
+    TFIMM_LAUNCH(fill_odd_bytes_kernel, dim3(grid_for((int64_t)bytes, 256)), dim3(256), 0, (hipStream_t)stream, (uint8_t*)dst, (uint8_t)b, bytes);
+  }
   return 0;
 }
 

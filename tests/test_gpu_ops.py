@@ -90,3 +90,33 @@ def test_mlp_fused_splits_oversize_tensors_into_row_chunks():
     env = dict(os.environ, TFIMM_MLP_LIMIT=str(1 << 20))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("nbytes,offset", [(196608, 0), (8, 0), (100, 0), (100, 3), (4099, 1)])
+def test_recorded_zeroing_writes_its_value_on_every_replay(nbytes, offset):
+    """tfimm_hip_memset_async recorded into a HIP graph (what a plan does in front of every squeeze-sum launch) must write its
+    value on EVERY replay.  The runtime's own hipMemsetAsync does not when recorded -- host memory from the second replay on
+    (tools/probes/memset_node_probe.py, profiles/r04_memset_node_probe.txt) -- so the entry point is a fill kernel for every size and
+    alignment, the odd ones included."""
+    import ctypes as C
+
+    import torch
+    from tfimm.engine import ffi
+    base = torch.empty(nbytes + 64, dtype=torch.uint8, device="cuda")
+    buf = base[offset:offset + nbytes]
+    for value in (0, 0x3c):
+        base.fill_(0x55)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            rc = ffi.lib.tfimm_hip_memset_async(C.c_void_p(buf.data_ptr()), value, nbytes,
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0
+        for r in range(4):
+            base.fill_(0x55)
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            assert int((buf != value).sum().item()) == 0, f"replay {r}: {nbytes} bytes at +{offset}, value {value:#x}"
+            assert int((base[:offset] != 0x55).sum().item()) == 0 and int((base[offset + nbytes:] != 0x55).sum().item()) == 0, \
+                f"replay {r}: bytes outside the range were written"
