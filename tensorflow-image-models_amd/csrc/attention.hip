@@ -939,14 +939,14 @@ static int launch_attn_stream(const AttnArgs& a, int64_t nseq, hipStream_t st) {
   const int nkp = (a.n + 63) / 64 * 64;
   const int krow = HD == 64 ? 8 : HD / 8 + 1;
   const size_t lds = (size_t)nkp * krow * 16 + (size_t)nkp * (HD / 8) * 16;
-  static bool attr_done = false;
+  static tfimm_once_t attr_done;
   static int cus = 256;
-  if (!attr_done) {
+  if (attr_done.need()) {
     TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)attn_stream_kernel<HD, NW, TQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
       cus = v;
-    attr_done = true;
+    attr_done.mark();
   }
   const int64_t items = nseq * a.heads;
   const int grid = (int)(items < cus ? items : cus);
@@ -967,11 +967,11 @@ template <int HD, bool SWIN, int NW, int TQ>
 static int launch_attn_resident(const AttnArgs& a, int64_t nseq, hipStream_t st) {
   const int nkp = (a.n + 63) / 64 * 64;
   const size_t lds = attn_resident_lds<HD>(a.n, SWIN, a.bias_log2 != nullptr);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static tfimm_once_t attr_done;
+  if (attr_done.need()) {
     TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)attn_resident_kernel<HD, SWIN, NW, TQ>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
+    attr_done.mark();
   }
   TFIMM_LAUNCH((attn_resident_kernel<HD, SWIN, NW, TQ>), dim3((unsigned)(nseq * a.heads)), dim3(NW * 64), lds, st, a, nkp);
   return 0;

@@ -360,12 +360,11 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p, const ThaWeig
       float l = l_run[hp] * __builtin_amdgcn_exp2f(m_run[hp] - m);
       l += __shfl_xor(l, 16, 64);
       l += __shfl_xor(l, 32, 64);
-      // The sums must be COMPLETE before the wave narrows EXEC for the store below.  hipcc sinks the last add into the
-      // `if (g == 0)` block and leaves its ds_bpermute_b32 in flight across the s_and_saveexec; when the LDS pipe is
-      // backed up (a GEMM workgroup of another stream on the same CU) the shuffle then executes under the NARROWED mask,
-      // lanes whose partner is disabled receive 0, and a query's 1 / sum misses two of its four key groups -- the round-3
-      // "co-residency defect" (profiles/NOTES_r04.md section 1; tools/tha_coresident_probe.py bperm).  Naming the values as
-      // asm operands forces the add, and with it the s_waitcnt lgkmcnt(0), in front of the branch.
+      // (Leftover of a REFUTED hypothesis, harmless: it was suspected that hipcc sinks the last add into the `if (g == 0)` block
+      // and that its ds_bpermute_b32 then executes under the narrowed EXEC mask.  The victim kernel built for it showed 0 wrong
+      // lanes and forcing the wait changed nothing (profiles/NOTES_r04.md section 1, "dead ends").  The cause of the round-3
+      // co-residency defect was the packed-fp32 op_sel form -- see the St / Wm comment further up and DESIGN.md section 3,
+      // rule 1.  The empty statement only pins the add in front of the branch.)
       asm volatile("" : "+v"(m), "+v"(l));
       if (g == 0) {
         const float il = 1.f / l;
@@ -497,10 +496,10 @@ __global__ void __launch_bounds__(256) tha_kernel(const ThaArgs p, const ThaWeig
 
 template <int H, int HG, int DT, bool QLDS>
 int launch_tha_q(const ThaArgs& a, const ThaWeights& w, size_t lds, hipStream_t st) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static tfimm_once_t attr_done;
+  if (attr_done.need()) {
     TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)tha_kernel<H, HG, DT, QLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
+    attr_done.mark();
   }
   const int64_t nblocks = (int64_t)a.batch * a.qchunks;
   if (nblocks > 0x7fffffffLL) TFIMM_FAIL(TFIMM_EINVAL, "talking_heads_attention: grid too large");
@@ -690,10 +689,10 @@ extern "C" int tfimm_hip_talking_heads_attention(const tfimm_tha_desc* dp, void*
   if ((d.hd != 32 && d.hd != 48) || !heads_built || ((uintptr_t)d.qkv & 15) || ((uintptr_t)d.out & 7)) {
     const size_t lds = (size_t)2 * d.heads * d.n_tokens * 4;
     if (lds > 160 * 1024) TFIMM_FAIL(TFIMM_EUNSUP, "talking_heads_attention: hd=%d heads=%d n=%d has no kernel", d.hd, d.heads, d.n_tokens);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static tfimm_once_t attr_done;
+    if (attr_done.need()) {
       TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)tha_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_done = true;
+      attr_done.mark();
     }
     const int64_t nb = (int64_t)d.batch * d.n_tokens;
     if (nb > 0x7fffffffLL) TFIMM_FAIL(TFIMM_EINVAL, "talking_heads_attention: grid too large");

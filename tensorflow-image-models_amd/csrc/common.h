@@ -46,6 +46,22 @@ void tfimm_set_error(const char* fmt, ...);
     TFIMM_LAUNCH_CHECK();                 \
   } while (0)
 
+// ---- one-time setup per (call site, device) ---------------------------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of a kernel ON ONE DEVICE: a host that drives several devices from one
+// process has to set it on each of them, and two host threads may arrive at the same call site at once.  A bit per device
+// ordinal (mod 64), set after the setup succeeded; a second thread that runs the setup concurrently repeats an idempotent call.
+#include <atomic>
+struct tfimm_once_t {
+  std::atomic<unsigned long long> done{0};
+  static unsigned long long bit() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return 1ull << (dev & 63);
+  }
+  bool need() const { return !(done.load(std::memory_order_acquire) & bit()); }
+  void mark() { done.fetch_or(bit(), std::memory_order_release); }
+};
+
 // ---- a workgroup barrier behind which OTHER waves overwrite LDS that THIS wave has been reading ----------------------
 // (an epilogue staging block that aliases the operand stage consumed last).  The wave's own LDS reads must be COMPLETE when it
 // signals arrival.  __builtin_amdgcn_s_barrier() does not order them: it is not a memory operation for hipcc, which issues

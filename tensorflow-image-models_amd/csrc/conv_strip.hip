@@ -514,10 +514,10 @@ __global__ void __launch_bounds__(256, 2) conv_strip_chain_kernel(const StripCha
 // host side: called by tfimm_hip_gemm for descriptors of exactly this shape (see gemm.hip: conv_strip_applies)
 int tfimm_launch_conv_strip(const tfimm_gemm::GemmArgs& g, int64_t a_bytes, int64_t w_bytes, int64_t out_bytes, int num_cu, hipStream_t stream) {
   using namespace tfimm_gemm;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static tfimm_once_t attr_done;        // per device, shared by host threads (common.h)
+  if (attr_done.need()) {
     TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)conv_strip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STRIP_LDS));
-    attr_done = true;
+    attr_done.mark();
   }
   StripArgs a;
   a.g = g;
@@ -550,10 +550,10 @@ int tfimm_launch_conv_strip_chain(const tfimm_chain_desc& d, int64_t M, int num_
   const bool relu = d.act1 == TFIMM_ACT_RELU && d.act2 == TFIMM_ACT_RELU;
   void (*fn)(const StripChainArgs) = relu ? (d.N2 == 512 ? conv_strip_chain_kernel<8, TFIMM_ACT_RELU> : conv_strip_chain_kernel<4, TFIMM_ACT_RELU>)
                                           : (d.N2 == 512 ? conv_strip_chain_kernel<8, -1> : conv_strip_chain_kernel<4, -1>);
-  static bool ready[2][2] = {};
-  if (!ready[relu][d.N2 == 512]) {
+  static tfimm_once_t ready[2][2];
+  if (ready[relu][d.N2 == 512].need()) {
     TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, STRIP_LDS));
-    ready[relu][d.N2 == 512] = true;
+    ready[relu][d.N2 == 512].mark();
   }
   int64_t grid = ((int64_t)num_cu * 2 + 7) / 8 * 8;
   const int64_t need = ((int64_t)a.n_tiles + 7) / 8 * 8;

@@ -259,11 +259,13 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
     g.out_vec = ((d.ldc & 3) == 0) && (((uintptr_t)d.out & 7) == 0);
 
   // ---- 3x3 / stride 1 / pad 1, 128 -> 128 channels, rows of at most 31 pixels (ResNet-50 stage 2): the input-strip kernel
-  //      (csrc/conv_strip.hip).  Tile hint 31 asks for it, hint 0 takes it unless TFIMM_STRIP_CONV=0; any other hint keeps
-  //      the implicit-GEMM tiles (the tuner's candidates).
+  //      (csrc/conv_strip.hip).  Tile hint 31 asks for it; hint 0 takes it unless TFIMM_STRIP_CONV=0 -- and only when its fixed
+  //      128-pixel x 128-channel tiles give every CU at least one (M >= 128 CUs: it was measured at 28 x 28 and batch >= 6;
+  //      below that the 128 x 64 / 256 x 32 implicit-GEMM tiles make more workgroups and the cost model decides); any other
+  //      hint keeps the implicit-GEMM tiles (the tuner's candidates).
   if (kmode == K_CONV && d.KH == 3 && d.KW == 3 && d.stride == 1 && g.stride_w == 1 && d.pad_t == 1 && d.pad_l == 1 && d.OH == d.H &&
       d.OW == d.W && d.Cin == 128 && g.cpitch == 128 && d.N == 128 && !d.residual && !d.out_f32 && g.out_vec16 && d.remap_in == 0 &&
-      !d.ln_stats && d.W <= 31 && d.ldw >= d.K && (d.tile_hint == 31 || (d.tile_hint == 0 && strip_conv_enabled()))) {
+      !d.ln_stats && d.W <= 31 && d.ldw >= d.K && (d.tile_hint == 31 || (d.tile_hint == 0 && strip_conv_enabled() && cdiv64(d.M, 128) >= num_cu()))) {
     const int64_t a_bytes = ((int64_t)d.B * d.H * d.W) * 128 * 2, w_bytes = (int64_t)d.N * d.ldw * 2;
     const int64_t out_bytes = ((int64_t)(d.M - 1) * d.ldc + d.N) * 2;
     if (a_bytes <= 0x7fffff00LL && w_bytes <= 0x7fffff00LL && out_bytes <= 0x7fffff00LL)
@@ -298,8 +300,8 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       // had been launched before, so the first forward of a model could differ in the last bits from its later ones:
       // tests/test_gpu_scored_batches.py under TFIMM_BRANCHES=2, cait_xxs24_224.)
       static int occ[TFIMM_GEMM_STREAM_NUM_TILES][2] = {};
-      static bool ready = false;
-      if (!ready) {
+      static tfimm_once_t ready;          // (attributes are per device; the occupancies are the same on every MI355X)
+      if (ready.need()) {
         for (int f = 0; f < 2; ++f)
           for (int e = 0; e < 3; ++e)
             for (int i = 0; i < TFIMM_GEMM_STREAM_NUM_TILES; ++i) {
@@ -314,7 +316,7 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
               nb = nb < 1 ? 1 : (nb > 4 ? 4 : nb);
               if (occ[i][f] == 0 || nb < occ[i][f]) occ[i][f] = nb;
             }
-        ready = true;
+        ready.mark();
       }
       int occ_f[TFIMM_GEMM_STREAM_NUM_TILES];
       for (int i = 0; i < TFIMM_GEMM_STREAM_NUM_TILES; ++i) occ_f[i] = occ[i][fi];
@@ -379,11 +381,13 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       if (ln_in) {
         const size_t lds = (size_t)t->lds_bytes + t->ln_lds;
         static int ln_occ[TFIMM_GEMM_STREAM_NUM_TILES] = {};
-        if (!ln_occ[ti]) {
+        static tfimm_once_t ln_ready[TFIMM_GEMM_STREAM_NUM_TILES];
+        if (ln_ready[ti].need()) {
           TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)t->fn_ln, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           int nb = 0;
           TFIMM_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)t->fn_ln, t->threads, lds));
           ln_occ[ti] = nb < 1 ? 1 : (nb > 4 ? 4 : nb);
+          ln_ready[ti].mark();
         }
         grid = ((int64_t)num_cu() * ln_occ[ti] + 7) / 8 * 8;
         if (grid > need) grid = need;
@@ -403,10 +407,10 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       ga.s_pieces = (int)cdiv64((int64_t)ga.s_slots * (ga.s_stride / 256), nw);
       const size_t lds = (size_t)t->lds_bytes + (size_t)2 * ga.s_pieces * nw * 1024;
       if (lds <= 160 * 1024 && nimg * d.K * 4 <= 0x7fffff00LL) {
-        static bool scale_attr[TFIMM_GEMM_STREAM_NUM_TILES][3] = {};
-        if (!scale_attr[ti][ei]) {
+        static tfimm_once_t scale_attr[TFIMM_GEMM_STREAM_NUM_TILES][3];
+        if (scale_attr[ti][ei].need()) {
           TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)t->fn_scale[ei], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          scale_attr[ti][ei] = true;
+          scale_attr[ti][ei].mark();
         }
         // resident workgroups per CU with the gate buffers counted in
         int occ_s = (int)((160 * 1024) / lds);
@@ -446,10 +450,10 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       if (nblocks > 0x7fffffffLL) TFIMM_FAIL(TFIMM_EINVAL, "gemm: grid too large");
       const size_t lds_bytes = (size_t)(t->bm + t->bn) * 128 * 2;
       gemm_dma_fn fn = t->fn[kmode == K_DENSE ? 0 : 1];
-      static bool dma_attr_done[TFIMM_GEMM_DMA_NUM_TILES][2] = {};
-      if (!dma_attr_done[ti][kmode == K_DENSE ? 0 : 1]) {
+      static tfimm_once_t dma_attr_done[TFIMM_GEMM_DMA_NUM_TILES][2];
+      if (dma_attr_done[ti][kmode == K_DENSE ? 0 : 1].need()) {
         TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        dma_attr_done[ti][kmode == K_DENSE ? 0 : 1] = true;
+        dma_attr_done[ti][kmode == K_DENSE ? 0 : 1].mark();
       }
       TFIMM_LAUNCH(fn, dim3((unsigned)nblocks), dim3(t->threads), lds_bytes, (hipStream_t)stream, ga);
       return 0;
@@ -469,10 +473,10 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
   if (nblocks > 0x7fffffffLL) TFIMM_FAIL(TFIMM_EINVAL, "gemm: grid too large");
   const size_t lds_bytes = (size_t)(t->bm + t->bn) * BK * 2 * 2;
   gemm_fn fn = t->fn[kmode];
-  static bool attr_done[TFIMM_GEMM_NUM_TILES][K_NUM] = {};
-  if (!attr_done[ti][kmode]) {
+  static tfimm_once_t attr_done[TFIMM_GEMM_NUM_TILES][K_NUM];
+  if (attr_done[ti][kmode].need()) {
     TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    attr_done[ti][kmode] = true;
+    attr_done[ti][kmode].mark();
   }
   TFIMM_LAUNCH(fn, dim3((unsigned)nblocks), dim3(t->threads), lds_bytes, (hipStream_t)stream, g);
   return 0;

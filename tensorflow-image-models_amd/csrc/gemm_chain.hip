@@ -136,11 +136,11 @@ extern "C" int tfimm_hip_conv_chain(const tfimm_chain_desc* dp, void* stream) {
                            : ri ? (vi ? gemm_chain_kernel<8, TFIMM_ACT_RELU> : gemm_chain_kernel<4, TFIMM_ACT_RELU>)
                                 : (vi ? gemm_chain_kernel<8> : gemm_chain_kernel<4>);
   const int lds = ChainGeom::LDS_BYTES;
-  static bool ready[2][3] = {};
+  static tfimm_once_t ready[2][3];
   const int fi = ds ? 2 : ri;
-  if (!ready[vi][fi]) {
+  if (ready[vi][fi].need()) {
     TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    ready[vi][fi] = true;
+    ready[vi][fi].mark();
   }
   int64_t grid = ((int64_t)chain_num_cu() * 2 + 7) / 8 * 8;      // two 4-wave workgroups per CU (80 KiB of LDS each)
   const int64_t need = ((int64_t)a.n_tiles + 7) / 8 * 8;

@@ -296,10 +296,10 @@ int launch_expand_dw_act(const MbArgs& a0, int B, hipStream_t st) {
   a.tiles_x = (a.OW + OTW - 1) / OTW;
   const int tiles_y = (a.OH + OTH - 1) / OTH;
   auto fn = expand_dw_kernel<K, S, OTH, OTW, ACT, STEM>;
-  static bool ready = false;
-  if (!ready) {
+  static tfimm_once_t ready;
+  if (ready.need()) {
     TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-    ready = true;
+    ready.mark();
   }
   TFIMM_LAUNCH(fn, dim3((unsigned)(a.tiles_x * tiles_y), (unsigned)B), dim3(G::NT), (size_t)G::LDS, st, a);
   return 0;

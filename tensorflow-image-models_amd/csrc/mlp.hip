@@ -518,10 +518,10 @@ extern "C" int tfimm_hip_mlp_fused(const tfimm_mlp_desc* dp, void* stream) {
   a.stamps = tfimm_mlp_stamps;
 #endif
   constexpr int lds = MlpGeom<128>::LDS_BYTES;
-  static bool ready = false;
-  if (!ready) {
+  static tfimm_once_t ready;
+  if (ready.need()) {
     TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)mlp_fused_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    ready = true;
+    ready.mark();
   }
   int64_t grid = ((int64_t)mlp_num_cu() + 7) / 8 * 8;
   const int64_t need = ((int64_t)a.n_tiles + 7) / 8 * 8;

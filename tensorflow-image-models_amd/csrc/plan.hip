@@ -145,19 +145,25 @@ int parse(const void* blob, size_t bytes, Plan& pl) {
   if ((int)r.get<uint32_t>() != tfimm_hip_abi_version()) TFIMM_FAIL(TFIMM_EINVAL, "plan: exported for another ABI version");
   pl.batch = r.get<uint32_t>();
   pl.img_h = r.get<int32_t>(); pl.img_w = r.get<int32_t>(); pl.img_c = r.get<int32_t>();
+  // every slab / constant is bounded (2^40 bytes: far above the 288 GB of an MI355X) and there are at most 2^32 of each, so the
+  // running workspace offset stays below 2^40 * 2^33 < 2^64 only if it is checked as well: a corrupted size near 2^64 would
+  // otherwise wrap `off` to a SMALL workspace_bytes while resolve() keeps comparing offsets against the huge slab size
+  constexpr uint64_t kMaxBuf = 1ull << 40;
   uint64_t off = 0;
   for (uint32_t i = 0, n = r.get<uint32_t>(); i < n && r.ok; ++i) {
     pl.slab_bytes.push_back(r.get<uint64_t>());
     pl.slab_off.push_back(off);
+    if (pl.slab_bytes.back() > kMaxBuf || off > kMaxBuf) TFIMM_FAIL(TFIMM_EINVAL, "plan: slab %u of %llu bytes", i, (unsigned long long)pl.slab_bytes.back());
     off += align256(pl.slab_bytes.back());
   }
   for (uint32_t i = 0, n = r.get<uint32_t>(); i < n && r.ok; ++i) {
     pl.const_bytes.push_back(r.get<uint64_t>());
     pl.const_src.push_back(r.get<uint64_t>());
     pl.const_off.push_back(off);
-    off += align256(pl.const_bytes.back());
     if (pl.const_bytes.back() > bytes || pl.const_src.back() > bytes - pl.const_bytes.back())      // (overflow-safe)
       TFIMM_FAIL(TFIMM_EINVAL, "plan: constant outside the blob");
+    if (pl.const_bytes.back() > kMaxBuf || off > kMaxBuf) TFIMM_FAIL(TFIMM_EINVAL, "plan: workspace too large");
+    off += align256(pl.const_bytes.back());
   }
   pl.workspace_bytes = off;
   for (uint32_t i = 0, n = r.get<uint32_t>(); i < n && r.ok; ++i) {
@@ -219,8 +225,17 @@ int parse(const void* blob, size_t bytes, Plan& pl) {
         pl.structs[pl.stem_struct].bytes.size() < sizeof(tfimm_stem_desc))
       TFIMM_FAIL(TFIMM_EINVAL, "plan: bad stem reference");
   }
-  for (const auto& o : pl.outputs)
-    if (o.slab >= pl.slab_off.size() || o.offset > pl.slab_bytes[o.slab]) TFIMM_FAIL(TFIMM_EINVAL, "plan: output '%s' outside its slab", o.name.c_str());
+  // an output is rows_per_image x batch rows of `cols` elements (bf16 or fp32) starting at `offset`: the whole extent inside its slab
+  for (const auto& o : pl.outputs) {
+    if (o.slab >= pl.slab_off.size()) TFIMM_FAIL(TFIMM_EINVAL, "plan: output '%s' outside its slab", o.name.c_str());
+    const uint64_t cap = pl.slab_bytes[o.slab], esz = o.dtype == 1 ? 4 : 2;
+    bool ok = o.offset < cap && o.cols > 0 && o.rows_per_image > 0 && o.cols <= kMaxBuf && o.rows_per_image <= kMaxBuf;
+    if (ok) {
+      const uint64_t rows = o.rows_per_image * (uint64_t)pl.batch;            // < 2^72 cannot happen: both factors bounded above
+      ok = rows <= kMaxBuf && rows * o.cols <= kMaxBuf && rows * o.cols * esz <= cap - o.offset;
+    }
+    if (!ok) TFIMM_FAIL(TFIMM_EINVAL, "plan: output '%s' outside its slab", o.name.c_str());
+  }
   // a descriptor argument must be at least as large as the struct its entry point reads
   for (const auto& c : pl.calls) {
     if (c.is_memset) continue;

@@ -673,10 +673,10 @@ int tfimm_hip_ref_talking_heads_attention(const tfimm_tha_desc* dp, void* stream
   memcpy(w.bw, d.proj_w_b, sizeof(float) * d.heads);
   const size_t lds = (size_t)2 * d.heads * d.n_tokens * 4;
   if (lds > 160 * 1024) TFIMM_FAIL(TFIMM_EUNSUP, "ref_talking_heads_attention: %d tokens x %d heads do not fit in LDS", d.n_tokens, d.heads);
-  static bool big_lds = false;
-  if (!big_lds) {      // cait_m36_384 / cait_m48_448: 576 / 784 tokens x 16 heads need 72 / 98 KiB
+  static tfimm_once_t big_lds;
+  if (big_lds.need()) {      // cait_m36_384 / cait_m48_448: 576 / 784 tokens x 16 heads need 72 / 98 KiB
     TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)ref_tha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    big_lds = true;
+    big_lds.mark();
   }
   REF_LAUNCH(ref_tha_kernel, (unsigned)(d.batch * d.n_tokens), 256, lds, stream, (const float*)d.qkv, (float*)d.out, d.n_tokens, d.heads,
              d.hd, d.scale, w);

@@ -986,10 +986,10 @@ static int launch_dwconv_rows(const bf16_t* x, const float* w, const float* bias
   // costs a wave per SIMD), TFIMM_DW_DEPTH=2 keeps it selectable for the swish flavour
   static const int depth = getenv("TFIMM_DW_DEPTH") ? atoi(getenv("TFIMM_DW_DEPTH")) : 1;
   auto go = [&](auto kern) -> int {
-    static bool attr_done = false;       // one flag per kernel instantiation (generic lambda)
-    if (!attr_done) {
+    static tfimm_once_t attr_done;       // one flag set per kernel instantiation (generic lambda)
+    if (attr_done.need()) {
       TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-      attr_done = true;
+      attr_done.mark();
     }
     TFIMM_LAUNCH(kern, dim3((unsigned)gx, (unsigned)B), dim3(256), lds, st, x, w, bias, y, sum_out, H, W, C, pad_t, pad_l, OH, OW, act,
                  rows_per_seg, nseg, CPB);
@@ -1488,10 +1488,10 @@ extern "C" int tfimm_hip_se_gate(const void* sums, int sums_fixed, float inv_cou
   if (!sums || !w1 || !w2 || !gate || B <= 0 || C <= 0 || rd <= 0) TFIMM_FAIL(TFIMM_EINVAL, "se_gate: bad arguments");
   const size_t lds = (size_t)SE_IMG * (C + rd) * sizeof(float);
   if (lds > 160 * 1024) TFIMM_FAIL(TFIMM_EUNSUP, "se_gate: C + rd = %d too large", C + rd);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static tfimm_once_t attr_done;
+  if (attr_done.need()) {
     TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)se_gate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
+    attr_done.mark();
   }
   TFIMM_LAUNCH(se_gate_kernel, dim3((B + SE_IMG - 1) / SE_IMG), dim3(1024), lds, (hipStream_t)stream, sums, sums_fixed, inv_count, w1, b1, w2, b2,
                gate, B, C, rd, act, gate_act);

@@ -311,12 +311,12 @@ extern "C" int tfimm_hip_stem_conv_pool(const tfimm_stem_desc* d, void* stream) 
   a.items = a.B * a.bands;
   static const int dbg = getenv("TFIMM_STEM_DBG") ? atoi(getenv("TFIMM_STEM_DBG")) : 0;
   a.dbg = dbg;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static tfimm_once_t attr_set;
+  if (attr_set.need()) {
     TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)stem_pool_kernel<kInPairs>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)stem_pool_kernel<kInBf16Rgb>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)stem_pool_kernel<kInF32Rgb>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    attr_set = true;
+    attr_set.mark();
   }
   const int grid = a.items < 2 * cus ? a.items : 2 * cus;
   const dim3 gd((unsigned)grid), bd(kThreads);

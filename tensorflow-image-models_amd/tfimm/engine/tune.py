@@ -50,10 +50,21 @@ def key_of(d) -> str:
 SCALE_CANDIDATES = CANDIDATES + (1, 2, 3, 4, 5, 6)
 
 
+def strip_shape(d) -> bool:
+    """The one shape the input-strip kernel (hint 31, csrc/conv_strip.hip) is built for -- what ``tfimm_hip_gemm`` checks
+    before it honours the hint: 3 x 3 / stride 1 / pad 1 convolution of 128 -> 128 channels, rows of at most 31 pixels, same
+    output size, no residual, bf16 output.  For any other shape the library answers hint 31 with its cost model, i.e. the
+    tuner would time hint 0 twice and could record 31 from noise (tests/test_tune_table.py rejects such entries)."""
+    return (int(d.mode) != 0 and d.KH == 3 and d.KW == 3 and d.stride == 1 and d.Cin == 128 and d.N == 128 and 0 < d.W <= 31
+            and getattr(d, "pad_t", 1) == 1 and getattr(d, "pad_l", 1) == 1 and getattr(d, "OH", d.H) == d.H
+            and getattr(d, "OW", d.W) == d.W and not d.residual and not d.out_f32 and not getattr(d, "a_scale", None))
+
+
 def candidates_for(d):
     if getattr(d, "ln_stats", None):
         return LN_CANDIDATES
-    return SCALE_CANDIDATES if getattr(d, "a_scale", None) else CANDIDATES
+    c = SCALE_CANDIDATES if getattr(d, "a_scale", None) else CANDIDATES
+    return c if strip_shape(d) else tuple(h for h in c if h != 31)
 
 
 def _parse_remap(spec: str):

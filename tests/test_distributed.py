@@ -80,3 +80,54 @@ def test_shard_bounds():
             assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _pipe_worker(rank, world, port, steps, q):
+    sys.path.insert(0, os.path.join(ROOT, "tensorflow-image-models_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tfimm.engine.dp import PipelinedGather
+        rows, cols = 3, 5
+        pg = PipelinedGather(rows, cols, torch.float32, "cpu", dist, depth=2)
+        ok, slots = True, []
+        local = torch.empty(rows, cols)
+        pending = None                 # (slot, step) whose result is read one step later: the exchange ran under the next step
+        for i in range(steps):
+            local.copy_(torch.arange(rows * cols, dtype=torch.float32).view(rows, cols) + 1000.0 * i + 100.0 * rank)
+            k = pg.submit(local)       # `local` may be overwritten right away: submit copies it into the send slot
+            slots.append(k)
+            if pending is not None:
+                got = pg.result(pending[0])
+                for r in range(world):
+                    want = torch.arange(rows * cols, dtype=torch.float32).view(rows, cols) + 1000.0 * pending[1] + 100.0 * r
+                    ok &= bool(torch.equal(got[r * rows:(r + 1) * rows], want))
+            pending = (k, i)
+        last = pg.last().clone()
+        pg.drain()
+        for r in range(world):
+            want = torch.arange(rows * cols, dtype=torch.float32).view(rows, cols) + 1000.0 * (steps - 1) + 100.0 * r
+            ok &= bool(torch.equal(last[r * rows:(r + 1) * rows], want))
+        q.put((rank, ok, slots))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_gather_delivers_every_step_in_order():
+    """The double-buffered asynchronous logits exchange (dp.PipelinedGather, what bench.py times over RCCL): the rows of
+    step i are read while step i + 1 has already been submitted, slots alternate, every rank sees every rank's rows."""
+    world, steps = 2, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipe_worker, args=(r, world, port, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, slots in res:
+        assert ok, f"rank {rank}: gathered rows differ from what the ranks submitted"
+        assert slots == [i % 2 for i in range(steps)]

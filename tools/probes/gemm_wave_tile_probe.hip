@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <vector>
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -252,6 +253,23 @@ static void run(const unsigned short* a, const unsigned short* b, float* out, lo
   const double us = ms * 1e3 / reps;
   printf("%-28s grid %4d  %8.1f us  %7.1f TFLOP/s  %6.0f cycles per k-tile (workgroup 0)  err=%s\n", name, grid, us,
          2.0 * M * N * K / us * 1e-6, (double)c / (K / 64), hipGetErrorString(hipGetLastError()));
+  // PROBE_SUSTAIN_MS: the same launch back to back for that long, bracketed by CLOCK_MONOTONIC stamps -- tools/power_probe.py
+  // lines its clock / power samples (Python's perf_counter is the same clock) up with the window
+  if (const char* sm = getenv("PROBE_SUSTAIN_MS")) {
+    const double want = atof(sm) * 1e-3;
+    auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+    hipDeviceSynchronize();
+    const double t0 = now();
+    long n = 0;
+    while (now() - t0 < want) {
+      for (int r = 0; r < 20; ++r) hipLaunchKernelGGL(fn, dim3(grid), dim3(WM * WN * 64), lds, 0, a, b, out, M, N, K, clk);
+      hipDeviceSynchronize();
+      n += 20;
+    }
+    const double t1 = now();
+    printf("SUSTAIN|%s|%.6f|%.6f|%.1f\n", name, t0, t1, 2.0 * M * N * K * n / (t1 - t0) * 1e-12);
+    fflush(stdout);
+  }
 }
 
 int main(int argc, char** argv) {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -76,6 +77,24 @@ int main(int argc, char** argv) {
     double flops = (double)blocks * (threads / 64) * iters * 8 * (mode >= 10 ? 16384.0 : 32768.0);
     printf("mode %d blocks %d: %.2f ms %.1f TF/s; clock64 %lld wall %lld -> shader clock %.0f MHz (if wall=100MHz); cycles/MFMA/wave %.1f\n",
            mode, blocks, ms, flops / ms / 1e9, h[0], h[1], 100.0 * h[0] / h[1], (double)h[0] / (iters * 8.0));
+  }
+  // PROBE_SUSTAIN_MS: the same launch back to back for that long between CLOCK_MONOTONIC stamps (tools/power_probe.py)
+  if (const char* sm = getenv("PROBE_SUSTAIN_MS")) {
+    const double want = atof(sm) * 1e-3;
+    auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+    hipDeviceSynchronize();
+    const double t0 = now();
+    long n = 0;
+    while (now() - t0 < want) {
+      if (mode == 10) k16<8><<<blocks, threads>>>(out, iters, clk, rnd); else if (mode == 11) k16<2><<<blocks, threads>>>(out, iters, clk, rnd);
+      else if (mode == 12) k16<4><<<blocks, threads>>>(out, iters, clk, rnd); else
+      if (mode == 0) k<8><<<blocks, threads>>>(out, iters, clk, rnd); else if (mode == 1) k<2><<<blocks, threads>>>(out, iters, clk, rnd); else k<4><<<blocks, threads>>>(out, iters, clk, rnd);
+      hipDeviceSynchronize();
+      ++n;
+    }
+    const double t1 = now();
+    const double flops = (double)blocks * (threads / 64) * iters * 8 * (mode >= 10 ? 16384.0 : 32768.0);
+    printf("SUSTAIN|mfma_peak mode %d %s operands|%.6f|%.6f|%.1f\n", mode, rnd ? "random" : "constant", t0, t1, flops * n / (t1 - t0) * 1e-12);
   }
   return 0;
 }
