@@ -175,7 +175,8 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
     captured = None
     if use_graph:
         try:
-            captured = plans[batch].capture(x)
+            # `sink`: the recording's last node writes the fp32 logits into `logits` -- a step is ONE hipGraphLaunch
+            captured = plans[batch].capture(x, sink=(out_t, logits))
         except RuntimeError as e:      # same launches one by one instead of one hipGraphLaunch; reported in config.launch
             print(f"warning: hipGraph recording failed ({e}); launching eagerly", file=sys.stderr)
             torch.cuda.synchronize()
@@ -188,7 +189,7 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
     if captured is not None and n_br > 1 and batch >= 2 * n_br and prog.supports_branches():
         from tfimm.engine.graph import CapturedBranches
         try:
-            forked = CapturedBranches(prog.make_branches(batch, n_br), x)
+            forked = CapturedBranches(prog.make_branches(batch, n_br), x, sink=(out_t, logits))
         except Exception as e:      # a recording that cannot be made must not cost the measurement: one branch
             print(f"warning: branch recording failed ({type(e).__name__}: {e}); one branch", file=sys.stderr)
             forked = None
@@ -211,7 +212,7 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
                 n_ops = len(prog.ops)
                 for frac in (0.5, 0.65, 0.8, 0.9):
                     try:
-                        hyb = CapturedHybrid(prog, x, max(1, int(round(frac * n_ops))))
+                        hyb = CapturedHybrid(prog, x, max(1, int(round(frac * n_ops))), sink=(out_t, logits))
                     except Exception as e:
                         print(f"warning: hybrid recording failed ({type(e).__name__}: {e})", file=sys.stderr)
                         torch.cuda.synchronize()
@@ -227,18 +228,17 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
     forked_bit_equal = None
     if forked is not None:
         captured.replay()
-        one = plans[batch].tensor_view(out_t).view(batch, out_t.C).float().clone()
+        one = logits.clone()
+        assert torch.equal(one, plans[batch].tensor_view(out_t).view(batch, out_t.C).float()), "recorded sink differs from the plan's output"
         forked.replay()
-        forked_bit_equal = bool(torch.equal(one, forked.output(out_t).view(batch, out_t.C).float()))
+        forked_bit_equal = bool(torch.equal(one, logits) and torch.equal(one, forked.output(out_t).view(batch, out_t.C).float()))
         torch.cuda.synchronize()
 
     def step(events=None):
         if forked is not None and events is None:
-            forked.replay()                                # one hipGraphLaunch: both branches
-            logits.copy_(forked.output(out_t).view(batch, out_t.C))
+            forked.replay()                                # one hipGraphLaunch: both branches + the logits into `logits`
         elif captured is not None and events is None:
-            captured.replay()                              # one hipGraphLaunch: the whole layer program
-            logits.copy_(plans[batch].tensor_view(out_t).view(batch, out_t.C))
+            captured.replay()                              # one hipGraphLaunch: the whole layer program + the logits into `logits`
         else:
             for s in range(0, batch, mb):
                 nb = min(mb, batch - s)

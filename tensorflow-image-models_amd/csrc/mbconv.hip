@@ -253,7 +253,17 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
       const int c0 = cc * 32 + cpl * 2;
       const bool cok = c0 < p.C && oxl < p.OW;
       tfimm_f32x2 tot = {0.f, 0.f};
-      bf16_t* yb = p.y + (((size_t)b * p.OH + oybl) * p.OW + oxl) * p.C + c0;
+      // Output stores through a buffer descriptor over THIS image (OH OW C elements, < 2 GiB: checked by the host): one 32-bit
+      // byte offset per thread, stepped by a uniform row pitch -- a channel pair / column outside the tensor gets an offset
+      // beyond the descriptor, rows >= OH run past its end by themselves, and the store is dropped.  The 64-bit row pointers
+      // of the first version did not fit into the 128 registers of four waves per SIMD next to the depthwise accumulators:
+      // hipcc spilled them and reloaded each in front of its store, and a scratch reload is a VMEM load -- `s_waitcnt vmcnt(0)`
+      // in front of every store waited for the write acknowledgement of the store before it (gfx9 retires VMEM in issue
+      // order), 12 round trips per thread and chunk.  No branches around the stores either, so they stay countable.
+      const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(
+          p.y + (size_t)b * p.OH * p.OW * p.C, 0, (int)((unsigned)p.OH * (unsigned)p.OW * (unsigned)p.C * 2u), 0x00020000);
+      const unsigned row_pitch = (unsigned)p.OW * (unsigned)p.C * 2u;
+      const unsigned yoff0 = cok ? (unsigned)(((oybl * p.OW + oxl) * p.C + c0) * 2) : 0x7fffff00u;
 #pragma unroll
       for (int r0 = 0; r0 < RPTL; r0 += 4) {
         tfimm_f32x2 v[4];
@@ -264,11 +274,10 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
         for (int e = 0; e < 4; ++e) {
           if (r0 + e < RPTL) {
             const uint32_t pk = pack_bf2(v[e][0], v[e][1]);
-            if (cok && oybl + r0 + e < p.OH) {
-              if (!(p.dbg & 1)) *reinterpret_cast<uint32_t*>(yb + (size_t)(r0 + e) * p.OW * p.C) = pk;
-              // the squeeze sees the stored (bf16-rounded) activations, as in tfimm_hip_dwconv
-              tot += tfimm_f32x2{__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)};
-            }
+            if (!(p.dbg & 1)) __builtin_amdgcn_raw_buffer_store_b32(pk, rs_y, (int)(yoff0 + (unsigned)(r0 + e) * row_pitch), 0, 0);
+            // the squeeze sees the stored (bf16-rounded) activations, as in tfimm_hip_dwconv
+            const uint32_t seen = (cok && oybl + r0 + e < p.OH) ? pk : 0u;
+            tot += tfimm_f32x2{__uint_as_float(seen << 16), __uint_as_float(seen & 0xffff0000u)};
           }
         }
       }
@@ -329,6 +338,7 @@ extern "C" int tfimm_hip_expand_dwconv(const tfimm_expand_dw_desc* d, void* stre
   if ((d->C & 1) || d->Cpad != (d->C + 31) / 32 * 32)
     TFIMM_FAIL(TFIMM_EINVAL, "expand_dwconv: C=%d must be even and Cpad=%d its multiple-of-32 ceiling", d->C, d->Cpad);
   if (d->B > 65535) TFIMM_FAIL(TFIMM_EUNSUP, "expand_dwconv: batch %d > 65535", d->B);
+  if ((int64_t)d->OH * d->OW * d->C * 2 > 0x7fffff00LL) TFIMM_FAIL(TFIMM_EUNSUP, "expand_dwconv: one image of the output exceeds 2 GiB");
   if ((((uintptr_t)d->x | (uintptr_t)d->w1 | (uintptr_t)d->b1) & 15) || ((uintptr_t)d->y & 3))
     TFIMM_FAIL(TFIMM_EINVAL, "expand_dwconv: x / w1 / b1 must be 16-byte aligned, y 4-byte aligned");
   if (d->pad_t < 0 || d->pad_l < 0 || d->pad_t >= d->k || d->pad_l >= d->k)

@@ -815,6 +815,11 @@ static int dw_rows_pairs_per_block(int cps, int sx) {
   return best;
 }
 
+// TFIMM_DW_ABLATE (probe builds only, tools/dw_diag.sh; 0 in the product): 1 no activation, 2 no multiply-adds, 4 no output
+// stores, 8 filter taps from registers instead of LDS -- which part of a row's work the launch time follows
+#ifndef TFIMM_DW_ABLATE
+#define TFIMM_DW_ABLATE 0
+#endif
 // ACT >= 0: that TFIMM_ACT_* with its parameters folded into the instructions; ACT < 0: `act` from the arguments
 template <int K, int S, int PX, int DEPTH, int ACT>
 __global__ void __launch_bounds__(256) dwconv_rows_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
@@ -873,11 +878,30 @@ __global__ void __launch_bounds__(256) dwconv_rows_kernel(const bf16_t* __restri
   int voff[COLS];
 #pragma unroll
   for (int col = 0; col < COLS; ++col) voff[col] = ((ox0 * S - pad_l + col) * C + c0) * 2;
-  auto load_row = [&](int r, uint32_t* dst) __attribute__((always_inline)) {
+  // Every VMEM instruction of the row loop is issued UNCONDITIONALLY and in a fixed order (loads of the row DEPTH ahead, then --
+  // in the phases that finish an output row -- its PX stores): what must not touch memory goes through a descriptor with zero
+  // records (a row beyond the segment, an output row of a neighbour segment) or has an offset beyond its row (columns right
+  // of the image).  VMEM operations retire in issue order on gfx9 (one vmcnt for loads AND stores), and with loads or stores
+  // inside branches hipcc cannot count them: the round-4 kernel waited `vmcnt(0)` at the top of every row, i.e. for the
+  // write acknowledgements of the previous row's stores (tools/dw_diag.sh: without the stores the k = 3 launches of
+  // EfficientNet-B4 ran 127 -> 71 us, the k = 5 ones 193 -> 160).  Now the wait in front of a row's first multiply leaves the
+  // younger stores in flight (s_waitcnt vmcnt(PX) in the steady state).
+  auto load_row = [&](int r, uint32_t* dst, bool valid) __attribute__((always_inline)) {
     const bf16_t* xrow = ximg + (size_t)min(max(r, 0), H - 1) * W * C;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xrow), 0, (int)row_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xrow), 0, valid ? (int)row_bytes : 0, 0x00020000);
 #pragma unroll
     for (int col = 0; col < COLS; ++col) dst[col] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, voff[col], 0, 0);
+  };
+  // output: a descriptor per output row (OW C elements); column ox0 + px >= OW has an offset beyond it
+  const unsigned orow_bytes = (unsigned)OW * (unsigned)C * 2u;
+  int ooff[PX];
+#pragma unroll
+  for (int px = 0; px < PX; ++px) ooff[px] = ((ox0 + px) * C + c0) * 2;
+  auto store_row = [&](int oy, const uint32_t* pk, bool valid) __attribute__((always_inline)) {
+    bf16_t* yrow = y + ((size_t)((size_t)b * OH + min(max(oy, 0), OH - 1)) * OW) * C;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(yrow, 0, valid ? (int)orow_bytes : 0, 0x00020000);
+#pragma unroll
+    for (int px = 0; px < PX; ++px) __builtin_amdgcn_raw_buffer_store_b32(pk[px], rs, ooff[px], 0, 0);
   };
   tfimm_f32x2 acc[NSLOT][PX];
 #pragma unroll
@@ -888,69 +912,75 @@ __global__ void __launch_bounds__(256) dwconv_rows_kernel(const bf16_t* __restri
   // 4-5 waves per SIMD, two do.  The phase loop is unrolled over lcm(PERIOD, 2) so the buffer index is a compile-time constant.
   constexpr int UNR = (DEPTH == 1 || PERIOD % 2 == 0) ? PERIOD : 2 * PERIOD;
   uint32_t raw[DEPTH][COLS];
-  load_row(r_begin, raw[0]);
-  if (DEPTH == 2 && r_begin + 1 < r_end) load_row(r_begin + 1, raw[DEPTH - 1]);
+  load_row(r_begin, raw[0], true);
+  if (DEPTH == 2) load_row(r_begin + 1, raw[DEPTH - 1], r_begin + 1 < r_end);
+  {
+    // PX stores that write nothing, behind the first loads: on EVERY path into the loop the row's loads now have at least PX
+    // younger VMEM operations, which is what lets the compiler's wait at the loop head be vmcnt(PX) instead of vmcnt(0)
+    const uint32_t zero[PX] = {};
+    store_row(0, zero, false);
+  }
   const tfimm_f32x2* wl = dw7_lds + cpl;
 
   for (int rb = r_begin; rb < r_end; rb += UNR) {
 #pragma unroll
     for (int ph2 = 0; ph2 < UNR; ++ph2) {
-      constexpr int dummy_unused = 0; (void)dummy_unused;
       const int ph = ph2 % PERIOD;
       const int r = rb + ph2;
-      if (r < r_end) {                               // wave-uniform
-        tfimm_f32x2 in[COLS];       // (rows outside the image are never multiplied: see the branch below)
+      const bool row_live = r < r_end;                 // wave-uniform; rows beyond the segment only run their (empty) VMEM
+      tfimm_f32x2 in[COLS];       // (rows outside the image are never multiplied: see the branch below)
 #pragma unroll
-        for (int col = 0; col < COLS; ++col)
-          in[col] = tfimm_f32x2{__uint_as_float(raw[ph2 % DEPTH][col] << 16), __uint_as_float(raw[ph2 % DEPTH][col] & 0xffff0000u)};
-        if (r + DEPTH < r_end) load_row(r + DEPTH, raw[ph2 % DEPTH]);   // DEPTH rows ahead, into the buffer just consumed
-        if ((unsigned)r < (unsigned)H) {
-          // input row r = r_begin + ph (mod PERIOD) feeds output row oy = (r + pad_t - ky) / S for the ky of its
-          // parity class (r_begin + pad_t is a multiple of S); oy lives in slot ((ph - ky) / S) mod NSLOT
+      for (int col = 0; col < COLS; ++col)
+        in[col] = tfimm_f32x2{__uint_as_float(raw[ph2 % DEPTH][col] << 16), __uint_as_float(raw[ph2 % DEPTH][col] & 0xffff0000u)};
+      load_row(r + DEPTH, raw[ph2 % DEPTH], r + DEPTH < r_end);   // DEPTH rows ahead, into the buffer just consumed
+      if (row_live && (unsigned)r < (unsigned)H) {
+        // input row r = r_begin + ph (mod PERIOD) feeds output row oy = (r + pad_t - ky) / S for the ky of its
+        // parity class (r_begin + pad_t is a multiple of S); oy lives in slot ((ph - ky) / S) mod NSLOT
 #pragma unroll
-          for (int ky = 0; ky < K; ++ky) {
-            if ((ky % S) != (ph % S)) continue;      // compile time
-            const int oy = (r + pad_t - ky) / S;
-            if (r + pad_t - ky >= 0 && oy >= oy0 && oy < oy1) {   // wave-uniform: other rows belong to a neighbour segment
-              const int slot = ((((ph - ky) / S) % NSLOT) + NSLOT) % NSLOT;
+        for (int ky = 0; ky < K; ++ky) {
+          if ((ky % S) != (ph % S)) continue;      // compile time
+          const int oy = (r + pad_t - ky) / S;
+          if (r + pad_t - ky >= 0 && oy >= oy0 && oy < oy1) {   // wave-uniform: other rows belong to a neighbour segment
+            const int slot = ((((ph - ky) / S) % NSLOT) + NSLOT) % NSLOT;
 #pragma unroll
-              for (int kx = 0; kx < K; ++kx) {
-                const tfimm_f32x2 wv = wl[(ky * K + kx) * CPB];
+            for (int kx = 0; kx < K; ++kx) {
+              const tfimm_f32x2 wv = (TFIMM_DW_ABLATE & 8) ? tfimm_f32x2{bias2.x + (float)(ky * K + kx), bias2.y} : wl[(ky * K + kx) * CPB];
 #pragma unroll
-                for (int px = 0; px < PX; ++px) acc[slot][px] = __builtin_elementwise_fma(in[px * S + kx], wv, acc[slot][px]);
+              for (int px = 0; px < PX; ++px) {
+                if (TFIMM_DW_ABLATE & 2) { if (kx == 0 && ky == 0) acc[slot][px] += in[px * S + kx] * wv; }
+                else acc[slot][px] = __builtin_elementwise_fma(in[px * S + kx], wv, acc[slot][px]);
               }
             }
           }
         }
-        // the output row whose LAST contribution (ky = K - 1) came from this input row is complete
-        if (((ph % S) == ((K - 1) % S))) {
-          constexpr int dslot_dummy = 0; (void)dslot_dummy;
-          const int dslot = ((((ph - (K - 1)) / S) % NSLOT) + NSLOT) % NSLOT;
-          const int oyd = (r + pad_t - (K - 1)) / S;
-          if (r + pad_t - (K - 1) >= 0 && oyd >= oy0 && oyd < oy1) {
-            bf16_t* yrow = y + ((size_t)((size_t)b * OH + oyd) * OW) * C + c0;
-            static_assert(PX == 4, "the activation runs on four packed pairs");
-            tfimm_f32x2 av[4] = {acc[dslot][0], acc[dslot][1], acc[dslot][2], acc[dslot][3]};
-            act8p(av, actp);            // packed (v_pk_*): the scalar form cost ~33 issue slots per pair for swish, this ~21
-            tfimm_f32x2 rowtot = {0.f, 0.f};
+      }
+      // the output row whose LAST contribution (ky = K - 1) came from this input row is complete
+      if (((ph % S) == ((K - 1) % S))) {
+        const int dslot = ((((ph - (K - 1)) / S) % NSLOT) + NSLOT) % NSLOT;
+        const int oyd = (r + pad_t - (K - 1)) / S;
+        const bool row_done = row_live && r + pad_t - (K - 1) >= 0 && oyd >= oy0 && oyd < oy1;     // wave-uniform
+        static_assert(PX == 4, "the activation runs on four packed pairs");
+        uint32_t pk[PX] = {};
+        if (row_done) {            // VALU only: the stores below are issued either way
+          tfimm_f32x2 av[4] = {acc[dslot][0], acc[dslot][1], acc[dslot][2], acc[dslot][3]};
+          if (!(TFIMM_DW_ABLATE & 1)) act8p(av, actp);            // packed (v_pk_*): the scalar form cost ~33 issue slots per pair for swish, this ~21
+          tfimm_f32x2 rowtot = {0.f, 0.f};
 #pragma unroll
-            for (int px = 0; px < PX; ++px) {
-              const uint32_t pk = pack_bf2(av[px][0], av[px][1]);
-              if (ox0 + px < OW) {
-                *reinterpret_cast<uint32_t*>(yrow + (size_t)(ox0 + px) * C) = pk;
-                // the squeeze sees the stored (bf16-rounded) activations
-                rowtot += tfimm_f32x2{__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)};
-              }
-            }
-            if (sum_out) {               // (wave-uniform) 64-bit conversion: a 32-bit one saturates silently at |row partial| = 32768
-              rowtot *= 65536.f;
-              tot0 += __float2ll_rn(rowtot.x);
-              tot1 += __float2ll_rn(rowtot.y);
-            }
+          for (int px = 0; px < PX; ++px) {
+            pk[px] = pack_bf2(av[px][0], av[px][1]);
+            // the squeeze sees the stored (bf16-rounded) activations of the columns inside the image
+            const uint32_t seen = (ox0 + px < OW) ? pk[px] : 0u;
+            rowtot += tfimm_f32x2{__uint_as_float(seen << 16), __uint_as_float(seen & 0xffff0000u)};
           }
-#pragma unroll
-          for (int px = 0; px < PX; ++px) acc[dslot][px] = bias2;
+          if (sum_out) {               // (wave-uniform) 64-bit conversion: a 32-bit one saturates silently at |row partial| = 32768
+            rowtot *= 65536.f;
+            tot0 += __float2ll_rn(rowtot.x);
+            tot1 += __float2ll_rn(rowtot.y);
+          }
         }
+        store_row(oyd, pk, row_done && !(TFIMM_DW_ABLATE & 4));
+#pragma unroll
+        for (int px = 0; px < PX; ++px) acc[dslot][px] = bias2;
       }
     }
   }

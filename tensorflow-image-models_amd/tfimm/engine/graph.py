@@ -1530,8 +1530,8 @@ class Plan:
             blob[off:off + len(b)] = b
         return bytes(blob)
 
-    def capture(self, x_dev, norm=None) -> "CapturedPlan":
-        return CapturedPlan(self, x_dev, norm)
+    def capture(self, x_dev, norm=None, sink=None) -> "CapturedPlan":
+        return CapturedPlan(self, x_dev, norm, sink=sink)
 
     def check_marshalling(self):
         """Convert every recorded argument through the ctypes prototypes (no launch): catches
@@ -1646,7 +1646,7 @@ class CapturedPlan:
     instead of ~100 ctypes calls + kernel launches.  The input pointer is baked into the graph, so
     callers either keep writing into ``static_input`` or replay on the tensor that was captured."""
 
-    def __init__(self, plan: "Plan", x_dev, norm=None):
+    def __init__(self, plan: "Plan", x_dev, norm=None, sink=None):
         import torch
         self.plan = plan
         self.static_input = x_dev
@@ -1659,6 +1659,7 @@ class CapturedPlan:
         # events (one process per GPU, RCCL initialised before the recording) must not invalidate the capture
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             plan.run(x_dev, norm=norm)       # (mean/std travel by value in the recorded launch)
+            _record_sink(sink, lambda t: plan.tensor_view(t))
 
     def replay(self):
         self.graph.replay()
@@ -1673,7 +1674,7 @@ class CapturedBranches:
     kernels never mix images).  Measured at the scored batch sizes (tools/two_stream_probe.py): ResNet-50 +6 %, Swin-B +12 %,
     EfficientNet-B4 +-0, ViT-B/16 -4 % -- callers pick per workload (bench.py --branches auto times both)."""
 
-    def __init__(self, plans: List["Plan"], x_dev, norm=None):
+    def __init__(self, plans: List["Plan"], x_dev, norm=None, sink=None):
         import torch
         self.plans = plans
         self.static_input = x_dev
@@ -1696,6 +1697,10 @@ class CapturedBranches:
                     p.run(x_dev[lo:hi], norm=norm)
             for s in self.side:
                 main.wait_stream(s)                          # join
+            if sink is not None:                             # each branch's rows straight into the caller's tensor
+                t, dst = sink
+                for p, (lo, hi) in zip(plans, self.slices):
+                    dst[lo:hi].copy_(p.tensor_view(t).view(dst[lo:hi].shape))
 
     def replay(self):
         self.graph.replay()
@@ -1714,7 +1719,7 @@ class CapturedHybrid:
     branches are built with those tensors ``external`` (their slice of the full tensor), so the join is free.  One
     ``hipGraphLaunch``, bit-equal results (tests/test_gpu_branches.py)."""
 
-    def __init__(self, prog: "Program", x_dev, cut_op: int, norm=None):
+    def __init__(self, prog: "Program", x_dev, cut_op: int, norm=None, sink=None):
         import torch
         B = x_dev.shape[0]
         assert 0 < cut_op <= len(prog.ops) and B >= 2
@@ -1752,12 +1757,22 @@ class CapturedHybrid:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             forward()
+            _record_sink(sink, lambda t: self.full.tensor_view(t))
 
     def replay(self):
         self.graph.replay()
 
     def output(self, t: "TRef"):
         return self.full.tensor_view(t)
+
+
+def _record_sink(sink, view):
+    """``sink = (TRef, tensor)``: the last node of a recording copies that program output into the caller's tensor, so a
+    replay delivers it with the same ``hipGraphLaunch`` -- no copy kernel between two replays (bench.py: the logits that the
+    exchange step sends; round 4 issued ``logits.copy_`` after every replay, a launch the next replay had to wait for)."""
+    if sink is not None:
+        t, dst = sink
+        dst.copy_(view(t).view(dst.shape))
 
 
 def _hip_memset_async(ptr: int, nbytes: int, stream_ptr: int) -> int:

@@ -146,3 +146,39 @@ def test_hybrid_recordings_reproduce_the_single_plan_bit_for_bit(name, batch):
         torch.cuda.synchronize()
         got = h.output(out_t).float().cpu().numpy()
         assert np.array_equal(got, want), (name, cut, float(np.abs(got - want).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,batch", [("resnet50", 8), ("vit_tiny_patch16_224", 6)])
+def test_recorded_sink_delivers_the_logits_with_the_replay(name, batch):
+    """``sink=(output, tensor)``: the recording's last node copies the program output into the caller's tensor, for the plain
+    recording, parallel branches and the hybrid -- the step bench.py times is then one hipGraphLaunch.  Every replay must leave
+    the bits of the eager forward there."""
+    import torch
+
+    import model_checks as mc
+    from tfimm.engine.graph import CapturedBranches, CapturedHybrid
+    model = tfimm.create_model(name)
+    model.set_weights(synthetic_weights(model, 2021))
+    x = torch.from_numpy(mc.make_input(model.cfg, batch)).cuda().to(torch.bfloat16)
+    prog = model.program()
+    out_t = prog.outputs["logits"]
+    plan = prog.make_plan(batch)
+    plan.run(x)
+    want = plan.tensor_view(out_t).view(batch, out_t.C).float().clone()
+    recs = []
+    for kind in ("plain", "branches", "hybrid"):
+        dst = torch.full((batch, out_t.C), float("nan"), dtype=torch.float32, device="cuda")
+        if kind == "plain":
+            rec = prog.make_plan(batch).capture(x, sink=(out_t, dst))
+        elif kind == "branches":
+            rec = CapturedBranches(prog.make_branches(batch, 2), x, sink=(out_t, dst))
+        else:
+            rec = CapturedHybrid(prog, x, max(1, len(prog.ops) // 2), sink=(out_t, dst))
+        recs.append((kind, rec, dst))
+    for kind, rec, dst in recs:
+        for _ in range(3):
+            dst.fill_(float("nan"))
+            rec.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(dst, want), kind
