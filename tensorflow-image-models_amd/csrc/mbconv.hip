@@ -53,7 +53,14 @@ struct MbGeom {
   static constexpr int X_BYTES = STEM ? (XIH * XIW * 8 + 15) / 16 * 16 : NPX * XP, E_BYTES = NPX * EP;
   static constexpr int KS = STEM ? 3 : 2;                      // MFMA k-steps of the expansion (K padded to 48 / 32)
   static constexpr int WD_FLOATS = (K * K + 1) * 32;
-  static constexpr int LDS = X_BYTES + E_BYTES + WD_FLOATS * 4 + 64 * 8;
+  static constexpr int WDN = (WD_FLOATS + NT - 1) / NT;         // tap / bias values each thread stages per chunk
+  // PF: a chunk's weights are requested one chunk ahead (see the kernel).  Stride-1 tiles only: measured on EfficientNet-B4 the
+  // stride-1 launches gain 7 % (518 -> 480 us), the stride-2 ones -- whose expansion phase is 4.4x their depthwise phase -- LOSE
+  // 7 - 11 % with it (897 -> 998, 440 -> 473 us; tools/mb_diag.py, one box), so they keep loading at the top of the chunk
+  static constexpr bool PF = S == 1;
+  static constexpr int B1_FLOATS = PF ? 512 : 0;                // expansion bias of EVERY chunk, staged once (Cpad <= 512: host check)
+  static constexpr int WD_LDS = PF ? WDN * NT : WD_FLOATS;      // floats of the tap region (PF: every thread writes its WDN values, no branch)
+  static constexpr int LDS = X_BYTES + E_BYTES + WD_LDS * 4 + 64 * 8 + B1_FLOATS * 4;
   static_assert(LDS <= 80 * 1024, "two workgroups per CU");
 };
 
@@ -66,7 +73,8 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
   unsigned char* Xs = mb_smem;
   unsigned char* Es = mb_smem + G::X_BYTES;
   float* Wd = reinterpret_cast<float*>(Es + G::E_BYTES);
-  tfimm_sq_t* lsum = reinterpret_cast<tfimm_sq_t*>(Wd + G::WD_FLOATS);      // 2 x 32 fixed-point squeeze sums
+  tfimm_sq_t* lsum = reinterpret_cast<tfimm_sq_t*>(Wd + G::WD_LDS);         // 2 x 32 fixed-point squeeze sums
+  float* B1s = reinterpret_cast<float*>(lsum + 64);                          // b1[Cpad]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int b = blockIdx.y;
   const int ty = blockIdx.x / p.tiles_x, tx = blockIdx.x - ty * p.tiles_x;
@@ -86,6 +94,7 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
       *reinterpret_cast<uint2*>(Xs + i * 8) = v;
     }
     if (tid < 64) lsum[tid] = 0;
+    if (G::PF && tid < p.Cpad) B1s[tid] = p.b1[tid];
   } else {
     const int nch = p.Cin >> 3;
     const bf16_t* xb = p.x + (size_t)b * p.H * p.W * p.Cin;
@@ -103,6 +112,7 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
       }
     }
     if (tid < 64) lsum[tid] = 0;
+    if (G::PF && tid < p.Cpad) B1s[tid] = p.b1[tid];
   }
   __syncthreads();          // the halo is read by other threads than the ones that staged it
   // which of this lane's halo pixels (one per block it expands) lie inside the image
@@ -117,7 +127,45 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
   const ActParams a1 = make_act(ACT >= 0 ? ACT : p.act1), a2 = make_act(ACT >= 0 ? ACT : p.act2);
   const int nchunks = p.Cpad >> 5;
 
-  for (int cc = 0; cc < nchunks; ++cc) {
+  // Weights of a chunk -- the expansion fragments (KS x 16 bytes per lane) and the taps + bias of the depthwise layer (WDN
+  // floats per thread) -- are requested ONE CHUNK AHEAD, at the start of the depthwise phase: in front of that phase's output
+  // stores in program order, so that (VMEM retiring in issue order) they do not wait for the stores' acknowledgements, and a
+  // whole phase early.  Loaded at the top of their own chunk they cost 7 - 11 % of the launch (tools/mb_diag.py: 890 -> 811,
+  // 514 -> 478, 440 -> 390 us with the loads removed).  The expansion bias of every chunk sits in LDS since phase 0.
+#ifndef TFIMM_MB_ABLATE
+#define TFIMM_MB_ABLATE 0      // probe builds (tools/mb_diag.py): 1 = every chunk multiplies with chunk 0's weights (timing only)
+#endif
+  uint4 af_n[G::KS];
+  float wd_n[G::WDN];
+  auto prefetch = [&](int c) __attribute__((always_inline)) {
+    const int cw = (TFIMM_MB_ABLATE & 1) ? 0 : min(c, nchunks - 1);       // (past the last chunk: the last one again, never used)
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) af_n[ks] = p.w1[(size_t)(cw * G::KS + ks) * 64 + lane];
+#pragma unroll
+    for (int u = 0; u < G::WDN; ++u) {
+      const int i = min(u * G::NT + tid, G::WD_FLOATS - 1);
+      const int t = i >> 5, ch = cw * 32 + (i & 31);
+      const float* src = t < K * K ? p.wdw + (size_t)t * p.Cpad + ch : p.b2 + ch;
+      wd_n[u] = *src;
+    }
+  };
+  if (G::PF) prefetch(0);
+  // As many stores that write nothing (offsets beyond a zero-record descriptor) as a depthwise phase issues stand behind the first
+  // prefetch: on both paths to the top of a chunk -- from the prologue and around the loop -- the prefetched weights are then
+  // followed by the same number of younger VMEM operations, and the compiler's wait for them is `vmcnt(RPT_FULL)`: the previous
+  // chunk's output stores stay in flight.  (It falls back to `vmcnt(0)` when the paths differ; that is also why a last chunk
+  // with the half-chunk mapping is peeled out of the loop below instead of being a second branch inside it.)
+  const __amdgpu_buffer_rsrc_t rs_none = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, 0, 0x00020000);
+  constexpr int RPT_FULL = OTH / ((G::NT / 16) / OTW);
+  auto empty_stores = [&](int n0, int n1) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = n0; e < n1; ++e) __builtin_amdgcn_raw_buffer_store_b32((unsigned)e, rs_none, (int)(0x7fffff00u + 64u * e), 0, 0);
+  };
+  if (G::PF) empty_stores(0, RPT_FULL);
+  constexpr bool HALF_OK = (G::NT / 8) % OTW == 0 && OTH % ((G::NT / 8) / OTW) == 0;
+  // a last chunk of at most 16 channels runs with the half-chunk mapping of the depthwise phase: peeled, behind the loop
+  const int n_loop = (HALF_OK && p.C - (nchunks - 1) * 32 <= 16) ? nchunks - 1 : nchunks;
+  auto chunk = [&](const int cc, auto half_tag) __attribute__((always_inline)) {
     // squeeze sums of the previous chunk: one global atomic per channel, then re-arm that half of the buffer
     if (p.sums && cc > 0 && tid < 32) {
       const int h = ((cc - 1) & 1) * 32 + tid, ch = (cc - 1) * 32 + tid;
@@ -126,20 +174,30 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
     }
     // ---- phase 1: expand + activation into LDS ------------------------------------------------------------------------
     bf16x8 af[G::KS];
-#pragma unroll
-    for (int ks = 0; ks < G::KS; ++ks) af[ks] = __builtin_bit_cast(bf16x8, p.w1[(size_t)(cc * G::KS + ks) * 64 + lane]);
     f32x4 bq[4];
+    if (G::PF) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 b4 = *reinterpret_cast<const float4*>(p.b1 + cc * 32 + q * 8 + hi * 4);
-      bq[q] = f32x4{b4.x, b4.y, b4.z, b4.w};
-    }
+      for (int ks = 0; ks < G::KS; ++ks) af[ks] = __builtin_bit_cast(bf16x8, af_n[ks]);
 #pragma unroll
-    for (int i0 = 0; i0 < G::WD_FLOATS; i0 += G::NT) {
-      const int i = i0 + tid;
-      if (i < G::WD_FLOATS) {
-        const int t = i >> 5, ch = cc * 32 + (i & 31);
-        Wd[i] = t < K * K ? p.wdw[(size_t)t * p.Cpad + ch] : p.b2[ch];
+      for (int u = 0; u < G::WDN; ++u) Wd[u * G::NT + tid] = wd_n[u];      // (read in phase 2, behind the barrier below; the region holds WDN NT floats)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f32x4*>(B1s + cc * 32 + q * 8 + hi * 4);
+    } else {
+      const int ccw = (TFIMM_MB_ABLATE & 1) ? 0 : cc;
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) af[ks] = __builtin_bit_cast(bf16x8, p.w1[(size_t)(ccw * G::KS + ks) * 64 + lane]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b4 = *reinterpret_cast<const float4*>(p.b1 + ccw * 32 + q * 8 + hi * 4);
+        bq[q] = f32x4{b4.x, b4.y, b4.z, b4.w};
+      }
+#pragma unroll
+      for (int i0 = 0; i0 < G::WD_FLOATS; i0 += G::NT) {
+        const int i = i0 + tid;
+        if (i < G::WD_FLOATS) {
+          const int t = i >> 5, ch = ccw * 32 + (i & 31);
+          Wd[i] = t < K * K ? p.wdw[(size_t)t * p.Cpad + ch] : p.b2[ch];
+        }
       }
     }
     const int nq = min(4, (p.C - cc * 32 + 7) >> 3);
@@ -211,6 +269,7 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
       }
     }
     __syncthreads();
+    if (G::PF) prefetch(cc + 1);
     // ---- phase 2: depthwise taps out of LDS ------------------------------------------------------------------------------
     // A last chunk of at most 16 channels (48 = 32 + 16, 144 = 4 x 32 + 16) would leave half of the 16 channel-pair columns
     // idle: it runs with 8 channel pairs x 64 pixel slots instead, every thread marching half as many rows.
@@ -274,7 +333,7 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
         for (int e = 0; e < 4; ++e) {
           if (r0 + e < RPTL) {
             const uint32_t pk = pack_bf2(v[e][0], v[e][1]);
-            if (!(p.dbg & 1)) __builtin_amdgcn_raw_buffer_store_b32(pk, rs_y, (int)(yoff0 + (unsigned)(r0 + e) * row_pitch), 0, 0);
+            if (!(TFIMM_PROBE(p.dbg) & 1)) __builtin_amdgcn_raw_buffer_store_b32(pk, rs_y, (int)(yoff0 + (unsigned)(r0 + e) * row_pitch), 0, 0);
             // the squeeze sees the stored (bf16-rounded) activations, as in tfimm_hip_dwconv
             const uint32_t seen = (cok && oybl + r0 + e < p.OH) ? pk : 0u;
             tot += tfimm_f32x2{__uint_as_float(seen << 16), __uint_as_float(seen & 0xffff0000u)};
@@ -286,11 +345,11 @@ __global__ __launch_bounds__(512, 4) void expand_dw_kernel(MbArgs p) {
         sq_add(&lsum[(cc & 1) * 32 + cpl * 2 + 1], sq_from_float(tot[1]));
       }
     };
-    constexpr bool HALF_OK = (G::NT / 8) % OTW == 0 && OTH % ((G::NT / 8) / OTW) == 0;
-    if (HALF_OK && p.C - cc * 32 <= 16) phase2(std::integral_constant<bool, HALF_OK>{});
-    else phase2(std::false_type{});
+    phase2(half_tag);
     __syncthreads();
-  }
+  };
+  for (int cc = 0; cc < n_loop; ++cc) chunk(cc, std::false_type{});
+  if (HALF_OK && n_loop < nchunks) chunk(n_loop, std::integral_constant<bool, HALF_OK>{});
   if (p.sums && tid < 32) {
     const int cl = nchunks - 1;
     const int ch = cl * 32 + tid;
@@ -338,6 +397,8 @@ extern "C" int tfimm_hip_expand_dwconv(const tfimm_expand_dw_desc* d, void* stre
   if ((d->C & 1) || d->Cpad != (d->C + 31) / 32 * 32)
     TFIMM_FAIL(TFIMM_EINVAL, "expand_dwconv: C=%d must be even and Cpad=%d its multiple-of-32 ceiling", d->C, d->Cpad);
   if (d->B > 65535) TFIMM_FAIL(TFIMM_EUNSUP, "expand_dwconv: batch %d > 65535", d->B);
+  if (d->Cpad > 512 && d->stride == 1)
+    TFIMM_FAIL(TFIMM_EUNSUP, "expand_dwconv: C=%d (at most 512 expanded channels at stride 1: their bias is staged in LDS)", d->C);
   if ((int64_t)d->OH * d->OW * d->C * 2 > 0x7fffff00LL) TFIMM_FAIL(TFIMM_EUNSUP, "expand_dwconv: one image of the output exceeds 2 GiB");
   if ((((uintptr_t)d->x | (uintptr_t)d->w1 | (uintptr_t)d->b1) & 15) || ((uintptr_t)d->y & 3))
     TFIMM_FAIL(TFIMM_EINVAL, "expand_dwconv: x / w1 / b1 must be 16-byte aligned, y 4-byte aligned");

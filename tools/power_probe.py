@@ -88,10 +88,15 @@ def main():
         tele.stop()
         for ln in out.splitlines():
             if ln.startswith("SUSTAIN|"):
-                _, name, t0, t1, tf = ln.split("|")
-                add(name, tf, "TFLOP/s", window(tele.samples, float(t0), float(t1)))
+                f = ln.split("|")
+                add(f[1], f[4], f[5] if len(f) > 5 else "TFLOP/s", window(tele.samples, float(f[2]), float(f[3])))
         return out
 
+    # energy coefficients: one resource at a time (tools/probes/energy_probe.hip)
+    if os.path.exists(os.path.join(BIN, "energy_probe")):
+        for mode in ("hbm_read", "hbm_read_zero", "hbm_write", "l2_read", "lds_read", "valu_fma", "valu_pk_fma", "valu_exp",
+                     "mfma_const", "mfma_rand"):
+            probe([os.path.join(BIN, "energy_probe"), mode])
     if os.path.exists(os.path.join(BIN, "mfma_peak")):
         probe([os.path.join(BIN, "mfma_peak"), "0", "256", "0"])
         probe([os.path.join(BIN, "mfma_peak"), "0", "256", "1"])
@@ -134,13 +139,23 @@ def main():
     cap = tele.src.cap() if tele.src is not None else None
     print(f"telemetry source: {tele.src.name if tele.src else None}; power cap {fmt(cap)} W; every load back to back for {sustain_ms} ms, "
           f"samples of the first 150 ms dropped\n")
-    print("| load | rate | shader clock MHz (mean, min..max over samples) | socket power W (mean, max) | W from the energy counter | share of the cap | samples |")
-    print("|---|---|---|---|---|---|---|")
+    idle_w = next((w["energy_power"] or w["power"] for name, _, _, w in rows if name == "idle"), None)
+    print("| load | rate | shader clock MHz (mean, min..max over samples) | socket power W (mean, max) | W from the energy counter | share of the cap | "
+          "pJ per unit above idle (B, flop, op) | samples |")
+    print("|---|---|---|---|---|---|---|---|")
     for name, rate, unit, w in rows:
         pw = w["energy_power"] if w["energy_power"] is not None else w["power"]
         share = "—" if (cap is None or pw is None) else f"{pw / cap:.2f}"
+        pj = "—"
+        try:
+            r = float(rate)
+            scale = {"TFLOP/s": 1e12, "GFLOP/s": 1e9, "GB/s": 1e9, "Gop/s": 1e9}.get(unit)
+            if scale and r > 0 and pw is not None and idle_w is not None:
+                pj = f"{(pw - idle_w) / (r * scale) * 1e12:.2f}"
+        except ValueError:
+            pass
         print(f"| {name} | {rate} {unit} | {fmt(w['sclk'])} ({fmt(w['sclk_min'])}..{fmt(w['sclk_max'])}) | {fmt(w['power'])} ({fmt(w['power_max'])}) | "
-              f"{fmt(w['energy_power'])} | {share} | {w['n']} |")
+              f"{fmt(w['energy_power'])} | {share} | {pj} | {w['n']} |")
 
 
 if __name__ == "__main__":
