@@ -803,13 +803,20 @@ __global__ void __launch_bounds__(256) dwconv_strip_kernel(const bf16_t* __restr
 // ---------------------------------------------------------------------------------------
 // channel pairs per workgroup (CPB) and with it column strips per workgroup (256 / CPB): the split of the 256
 // threads that wastes the fewest on channel-tile, strip-group and rounding remainders
-static int dw_rows_pairs_per_block(int cps, int sx) {
+// k <= 3 (9 MACs per output: the launch follows its memory traffic, not its arithmetic): a tile whose run of channels per pixel is
+// a whole number of 64-byte segments (16 pairs) is worth more than the last few percent of busy threads -- C = 672 at 24 x 24
+// with tiles of 85 pairs (340-byte runs that start anywhere) 118 us, with 112 or 128 pairs 97 us, C = 2688 at 12 x 12 111 -> 94 us
+// with 80 pairs; the k = 5 / 7 launches, bound by their multiply-adds, lose with any tile but the fullest (tools/dw_diag.py,
+// TFIMM_DW_CPB / TFIMM_DW_ALIGN_BONUS).  The bonus (20 % of the thread utilisation) applies to tiles of at least 80 pairs.
+static int dw_rows_pairs_per_block(int cps, int sx, int k) {
+  static const double bonus = getenv("TFIMM_DW_ALIGN_BONUS") ? atof(getenv("TFIMM_DW_ALIGN_BONUS")) : 0.2;
   int best = cps < 128 ? cps : 128;
   double best_u = -1.0;
   for (int c = 8; c <= 128 && c <= cps; ++c) {
     const int spb = 256 / c;
     const int ct = (cps + c - 1) / c, sg = (sx + spb - 1) / spb;
-    const double u = ((double)cps / (ct * c)) * ((double)sx / (sg * spb)) * (c * spb / 256.0);
+    double u = ((double)cps / (ct * c)) * ((double)sx / (sg * spb)) * (c * spb / 256.0);
+    if (k <= 3 && (c % 16) == 0 && c >= 80) u *= 1.0 + bonus;      // (short runs lose: C = 144 with tiles of 32 pairs 425 us against 340)
     if (u > best_u + 1e-9 || (u > best_u - 1e-9 && c > best)) { best_u = u; best = c; }
   }
   return best;
@@ -1001,7 +1008,8 @@ static int launch_dwconv_rows(const bf16_t* x, const float* w, const float* bias
   constexpr int PX = 4;
   const int cps = C / 2;
   const int sx = (OW + PX - 1) / PX;
-  const int CPB = dw_rows_pairs_per_block(cps, sx), SPB = 256 / CPB;
+  static const int cpb_env = getenv("TFIMM_DW_CPB") ? atoi(getenv("TFIMM_DW_CPB")) : 0;      // (probe: force the channel-pair tile)
+  const int CPB = (cpb_env >= 8 && cpb_env <= 128 && cpb_env <= cps) ? cpb_env : dw_rows_pairs_per_block(cps, sx, K), SPB = 256 / CPB;
   const int ctiles = (cps + CPB - 1) / CPB;
   const int sgroups = (sx + SPB - 1) / SPB;
   // row segments cost K - S halo rows each: split only until every CU has its three resident workgroups
