@@ -99,6 +99,9 @@ PY
         timeout 300 python tools/op_profile.py $m > $O/opprof_$m.log 2>&1; echo "opprof $m rc=$?"; cp gpurun_out/opprof_$m.txt $O/ 2>/dev/null; head -1 $O/opprof_$m.txt
       done
       for m in $WLS; do
+        timeout 300 python tools/op_power.py $m > $O/oppower_$m.log 2>&1; echo "oppower $m rc=$?"; cp gpurun_out/oppower_$m.txt $O/ 2>/dev/null; head -1 $O/oppower_$m.txt | cut -c1-200
+      done
+      for m in $WLS; do
         bash tools/gpu_mfma_busy.sh $m > /dev/null 2>&1; cp gpurun_out/mfma_busy_$m.txt $O/ 2>/dev/null; head -6 $O/mfma_busy_$m.txt | cut -c1-170
         [ -z "${NO_PIPE:-}" ] && { bash tools/gpu_pipe_busy.sh $m > /dev/null 2>&1; cp gpurun_out/pipe_busy_$m.txt $O/ 2>/dev/null; }
       done

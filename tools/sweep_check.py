@@ -22,7 +22,16 @@ for f in sorted(glob.glob(os.path.join(d, "*.npy"))):
     m = tfimm.create_model(name)
     w = synthetic_weights(m, 2021)
     x = mc.make_input(m.cfg, 2, 2021)
-    ref = oracle.forward(m.cfg, w, x)
+    # SWEEP_REF_CACHE: directory of oracle logits computed earlier (tools/sweep_check.py --refs fills it while the GPU box is busy)
+    cache = os.environ.get("SWEEP_REF_CACHE")
+    cpath = os.path.join(cache, name + ".npy") if cache else None
+    if cpath and os.path.exists(cpath):
+        ref = np.load(cpath)
+    else:
+        ref = oracle.forward(m.cfg, w, x)
+        if cpath:
+            os.makedirs(cache, exist_ok=True)
+            np.save(cpath, np.asarray(ref, dtype=np.float32))
     got = np.load(f).reshape(ref.shape)
     err = mc.rel_err(got, ref)
     agree = float((got.argmax(-1) == ref.argmax(-1)).mean())
