@@ -14,6 +14,11 @@ shader clocks, socket power, the firmware's energy accumulator -- the latter giv
 independently of the sampling rate), (2) the amdgpu hwmon files under /sys/class/drm/card*/device/hwmon, (3) one
 ``rocm-smi --json`` call per sample (slow: a few Hz).  Nothing here is on the product path and nothing raises: a box
 without any source yields ``{"source": None, "error": ...}`` and the bench line says so.
+
+The sampler runs in a CHILD PROCESS by default (``python telemetry.py --serve``, one per device, commands over a pipe): the
+management library is then never loaded into the process that drives the GPU -- a fault inside it (one bench run of this round
+died with SIGSEGV and an empty output while sampling in-process) costs the telemetry, not the measurement.  Time stamps are
+CLOCK_MONOTONIC in both processes.  ``TFIMM_TELEMETRY=inproc`` samples on a thread of the calling process, ``=off`` disables it.
 (The reference's own harness has neither synchronisation nor telemetry: tfimm/utils/profile.py:30-42.)
 """
 import glob
@@ -192,22 +197,113 @@ def torch_bus_id(device_index=0):
         return None
 
 
+class _Child:
+    """The sampler as a child process: ``start`` / ``stop`` / ``cap`` over its stdin, one JSON line back per command."""
+
+    def __init__(self, device_index, bus_id, hz):
+        import subprocess
+        import sys
+        self.p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--serve", str(device_index), bus_id or "-", str(hz)],
+                                  stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, bufsize=1)
+        hello = self._read(20.0)
+        if not hello or hello.get("source") is None:
+            why = (hello or {}).get("error", "the sampler process did not answer")
+            self.close()
+            raise RuntimeError(why)
+        self.name = hello["source"] + " (child process)"
+        self._cap = hello.get("cap")
+
+    def _read(self, timeout):
+        import select
+        r, _, _ = select.select([self.p.stdout], [], [], timeout)
+        if not r:
+            return None
+        line = self.p.stdout.readline()
+        try:
+            return json.loads(line) if line else None
+        except ValueError:
+            return None
+
+    def ask(self, cmd, timeout=5.0):
+        try:
+            self.p.stdin.write(cmd + "\n")
+            self.p.stdin.flush()
+        except (OSError, ValueError):
+            return None
+        return self._read(timeout)
+
+    def cap(self):
+        return self._cap
+
+    def close(self):
+        try:
+            self.p.stdin.close()
+            self.p.terminate()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def _serve(argv):
+    """``telemetry.py --serve <device> <bus id | -> <hz>``: the child's main loop."""
+    import sys
+    dev, bus, hz = int(argv[0]), (None if argv[1] == "-" else argv[1]), float(argv[2])
+    src, why = open_source(dev, bus)
+    out = sys.stdout
+    out.write(json.dumps(dict(source=None if src is None else src.name, cap=None if src is None else src.cap(), error="; ".join(why))) + "\n")
+    out.flush()
+    if src is None:
+        return
+    t = Telemetry(dev, hz=hz, source=src)
+    for line in sys.stdin:
+        cmd = line.strip()
+        if cmd == "start":
+            t.start()
+            out.write("{}\n")
+        elif cmd in ("stop", "stop_raw"):
+            t.stop()
+            ans = dict(summary=t.summary(), t0=t.t0, t1=t.t1)
+            if cmd == "stop_raw":
+                ans["samples"] = t.samples
+            out.write(json.dumps(ans) + "\n")
+        elif cmd == "quit":
+            break
+        else:
+            out.write("{}\n")
+        out.flush()
+
+
 class Telemetry:
-    """Samples shader clock and socket power of one GPU on a side thread between ``start()`` and ``stop()``."""
+    """Samples shader clock and socket power of one GPU between ``start()`` and ``stop()`` (child process by default; a side
+    thread of this process when a ``source`` object is given or TFIMM_TELEMETRY=inproc)."""
     # firmware units of the MI300-class gpu_metrics table: energy_accumulator 15.259 uJ, firmware_timestamp 10 ns
     ENERGY_UJ = 15.259
     FW_TICK_S = 1e-8
     _shared = {}
 
-    def __init__(self, device_index=0, hz=200.0, source=None):
+    def __init__(self, device_index=0, hz=200.0, source=None, raw=False):
         self.period = 1.0 / hz
+        self.child = None
+        self.raw = raw                      # child mode: bring the samples over as well (tools/power_probe.py cuts its own windows)
+        self._summary = None
+        mode = os.environ.get("TFIMM_TELEMETRY", "proc")
         if source is not None:
             self.src, self.why = source, []
-        else:
+        elif mode == "off":
+            self.src, self.why = None, ["TFIMM_TELEMETRY=off"]
+        elif mode == "inproc":
             key = device_index
             if key not in Telemetry._shared:            # one handle per process and device: amdsmi_init is not cheap
                 Telemetry._shared[key] = open_source(device_index, torch_bus_id(device_index))
             self.src, self.why = Telemetry._shared[key]
+        else:
+            key = ("child", device_index, hz)
+            if key not in Telemetry._shared:
+                try:
+                    Telemetry._shared[key] = (_Child(device_index, torch_bus_id(device_index), hz), [])
+                except Exception as e:  # noqa: BLE001
+                    Telemetry._shared[key] = (None, [f"sampler process: {type(e).__name__}: {e}"])
+            self.child, self.why = Telemetry._shared[key]
+            self.src = self.child
         self.samples = []
         self._stop = threading.Event()
         self._thread = None
@@ -231,8 +327,14 @@ class Telemetry:
 
     def start(self):
         self.samples = []
+        self._summary = None
         self._stop.clear()
         self.t0 = time.perf_counter()
+        if self.child is not None:
+            if self.child.ask("start") is None:           # the sampler died: keep measuring without it
+                self.why = ["the sampler process stopped answering"]
+                self.child = self.src = None
+            return self
         if self.src is not None:
             self._thread = threading.Thread(target=self._loop, name="tfimm-telemetry", daemon=True)
             self._thread.start()
@@ -240,6 +342,15 @@ class Telemetry:
 
     def stop(self):
         self.t1 = time.perf_counter()
+        if self.child is not None:
+            ans = self.child.ask("stop_raw" if self.raw else "stop", timeout=10.0)
+            if not ans or "summary" not in ans:
+                self.why = ["the sampler process stopped answering"]
+                self.child = self.src = None
+            else:
+                self._summary = ans["summary"]
+                self.samples = ans.get("samples", [])
+            return self
         self._stop.set()
         if self._thread is not None:
             self._thread.join(timeout=5.0)
@@ -253,7 +364,9 @@ class Telemetry:
         return False
 
     def summary(self, digits=1):
-        if self.src is None:
+        if self._summary is not None:
+            return self._summary
+        if self.src is None or self.child is not None:
             return dict(source=None, error="; ".join(self.why) or "no telemetry source")
         ss = self.samples
         out = dict(source=self.src.name, samples=len(ss), window_s=round((self.t1 or time.perf_counter()) - self.t0, 4))
@@ -290,3 +403,9 @@ class Telemetry:
         cap = self.src.cap()
         out["power_cap_w"] = None if cap is None else round(cap, digits)
         return out
+
+
+if __name__ == "__main__":
+    import sys
+    if len(sys.argv) >= 5 and sys.argv[1] == "--serve":
+        _serve(sys.argv[2:5])

@@ -10,7 +10,7 @@ from tfimm.utils.telemetry import Telemetry
 
 shapes = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [(336, 48, 5, 1), (672, 24, 3, 1), (960, 24, 5, 1), (1632, 12, 5, 1), (2688, 12, 3, 1)]
 B = 256
-tele = Telemetry(0, hz=250.0)
+tele = Telemetry(0, hz=250.0, raw=True)
 for C, Hh, k, s in shapes:
     x = torch.randn(B, Hh, Hh, C, device="cuda").to(torch.bfloat16)
     w = torch.randn(k * k, C, device="cuda") * 0.2

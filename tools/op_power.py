@@ -41,7 +41,7 @@ def main():
     torch.cuda.synchronize()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     idx = plan._input_patch[0]
-    tele = Telemetry(0, hz=250.0)
+    tele = Telemetry(0, hz=250.0, raw=True)
     tele.start(); time.sleep(0.5); tele.stop()
     idle = [s["power"] for s in tele.samples if s.get("power") is not None]
     idle_w = sum(idle) / max(len(idle), 1)

@@ -44,7 +44,7 @@ def main():
     import torch
     from tfimm.utils.telemetry import Telemetry
     torch.cuda.init()
-    tele = Telemetry(0, hz=250.0)
+    tele = Telemetry(0, hz=250.0, raw=True)
     rows = []
 
     def fmt(v, d=0):

@@ -47,14 +47,14 @@ __global__ void __launch_bounds__(256) k_lds(unsigned* out, int iters) {
   for (int i = threadIdx.x; i < 4096; i += 256) { h = h * 1664525u + 1013904223u; buf[i] = u32x4{h, ~h, h * 7u, h ^ 0x5bd1e995u}; }
   __syncthreads();
   unsigned s = 0;
-  int idx = threadIdx.x;
+  unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)&buf[threadIdx.x];
   for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const u32x4 v = buf[(idx + u * 256) & 4095];
-      s += v.x ^ v.y ^ v.z ^ v.w;
-    }
-    idx = (idx + 2048 + (s & 0)) & 4095;
+    u32x4 v0, v1, v2, v3, v4, v5, v6, v7;
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:4096\n\tds_read_b128 %2, %8 offset:8192\n\tds_read_b128 %3, %8 offset:12288\n\t"
+                 "ds_read_b128 %4, %8 offset:16384\n\tds_read_b128 %5, %8 offset:20480\n\tds_read_b128 %6, %8 offset:24576\n\tds_read_b128 %7, %8 offset:28672\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7) : "v"(addr) : "memory");
+    s += v0.x ^ v1.y ^ v2.z ^ v3.w ^ v4.x ^ v5.y ^ v6.z ^ v7.w;
   }
   if (s == 0x12345u) out[0] = s;
 }
