@@ -63,6 +63,12 @@ PEAK = {"hbm": (8000.0, "GB/s"), "mfma": (2500.0, "TFLOP/s")}   # MI355X_MICROAR
 # algorithmic activation bytes per image -- the HBM-roofline numerator
 ALG_BYTES_PER_IMAGE = {"resnet50": 56.8e6, "swin_base_patch4_window7_224": 140.1e6, "efficientnet_b4": 205.2e6,
                        "vit_base_patch16_224": 80.8e6, "vit_tiny_patch16_224": 20.4e6}
+# Energy coefficients of this part, measured with one resource busy at a time (profiles/r05_power.md, tools/probes/energy_probe.hip):
+# joules above the idle floor per bf16 MFMA flop on random operands and per byte of HBM traffic (reads 0.14, writes 0.17 nJ/B on
+# random data).  Every workload here runs at 0.88 .. 0.97 of the 1400-W socket cap, so a step cannot take less than
+# (flops x E_MFMA + algorithmic bytes x E_HBM) / (cap - idle): the `energy` object of a workload states that floor next to the
+# joules the step really took (mean socket power of the sustained window x its time per step).
+E_MFMA_PJ_PER_FLOP, E_HBM_NJ_PER_BYTE, P_IDLE_W = 0.62, 0.15, 255.0
 FAMILY_KERNELS = {"gemm": "tfimm_gemm::* (every GEMM / convolution flavour, incl. the fused bottleneck tail) + stem_pool_kernel",
                   "attention": "attn_*_kernel", "dwconv": "dwconv_*_kernel + expand_dw_kernel (fused expansion + depthwise)"}
 
@@ -450,6 +456,28 @@ def roofline_of(name, wl, r, steps, batch):
                        "share_of_eager_step compares with the wall time of those eager steps")
 
 
+def energy_of(name, flops_img, batch, weight_bytes, sustained):
+    """Joules per step against the floor the part's energy coefficients set (None without telemetry or byte count)."""
+    tl = (sustained or {}).get("telemetry") or {}
+    pw = tl.get("energy_power_w") or tl.get("power_w_mean")
+    cap = tl.get("power_cap_w")
+    alg = ALG_BYTES_PER_IMAGE.get(name)
+    if not pw or not cap or not alg:
+        return None
+    ms = sustained["ms_per_step"]
+    flops, byts = flops_img * batch, alg * batch + weight_bytes
+    floor_j = flops * E_MFMA_PJ_PER_FLOP * 1e-12 + byts * E_HBM_NJ_PER_BYTE * 1e-9
+    dyn_j = (pw - P_IDLE_W) * ms * 1e-3
+    floor_ms = floor_j / (cap - P_IDLE_W) * 1e3
+    return dict(joules_per_step=round(pw * ms * 1e-3, 3), joules_per_image=round(pw * ms * 1e-3 / batch, 5),
+                dynamic_joules_per_step=round(dyn_j, 3), floor_dynamic_joules=round(floor_j, 3), frac=round(floor_j / dyn_j, 4),
+                floor_ms_per_step_at_the_cap=round(floor_ms, 3), floor_images_per_sec_at_the_cap=round(batch / floor_ms * 1e3, 1),
+                power_w=pw, power_cap_w=cap, share_of_cap=round(pw / cap, 3),
+                model=f"floor = matmul flops x {E_MFMA_PJ_PER_FLOP} pJ + algorithmic bytes x {E_HBM_NJ_PER_BYTE} nJ (single-resource probes of "
+                      f"profiles/r05_power.md; VALU work -- depthwise multiply-adds, activations, softmax -- not counted, so it is a "
+                      f"lower bound); dynamic = above the {P_IDLE_W:.0f}-W idle floor; measured over the sustained window of the timed recording")
+
+
 def usable_cores():
     """CPU threads this process may really use: affinity mask capped by the cgroup quota
     (a GPU box reports 256 logical CPUs but the container gets far fewer)."""
@@ -700,6 +728,7 @@ def run_workload(name, args, world, rank, dist, steps, warmup, batch=0, micro_ba
                    power_cap_w=r["telemetry"].get("power_cap_w"), telemetry=r["telemetry"], sustained=r["sustained"],
                    exchange_mode=r["exchange_mode"],
                    roofline=rl)
+        out["energy"] = energy_of(name, flops_img, batch, prog.weight_bytes(), r["sustained"])
         if with_cpu:
             cpu, xs, ys, fs = cpu_baseline(model, wl["model"], target_seconds=cpu_seconds, parity_images=parity_images)
             out["cpu_baseline"] = cpu

@@ -425,6 +425,8 @@ extern "C" int tfimm_hip_expand_dwconv(const tfimm_expand_dw_desc* d, void* stre
     return launch_expand_dw_act<3, 1, 12, 32, -1, true>(a, d->B, st);
   }
   if (d->k == 3 && d->stride == 1) return launch_expand_dw<3, 1, 12, 32>(a, d->B, st);
+  // (8 x 16 outputs per tile at stride 2: 6 x 16 balances the expansion phase over the waves better -- 14 pixel blocks instead of
+  //  18 on 8 waves -- and is 12 % slower, 4 x 16 33 %: the halo overhead decides; tools/mb_diag.py)
   if (d->k == 3 && d->stride == 2) return launch_expand_dw<3, 2, 8, 16>(a, d->B, st);
   if (d->k == 5 && d->stride == 2) return launch_expand_dw<5, 2, 6, 16>(a, d->B, st);
   TFIMM_FAIL(TFIMM_EUNSUP, "expand_dwconv: k=%d stride=%d (3 or 5, stride 1 or 2)", d->k, d->stride);

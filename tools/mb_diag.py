@@ -11,7 +11,7 @@ from tfimm.engine import pack
 from tfimm.utils.telemetry import Telemetry
 
 B = int(os.environ.get("MB_BATCH", "256"))
-shapes = [(24, 144, 3, 2, 190), (32, 192, 3, 1, 95), (32, 192, 5, 2, 95)]
+shapes = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [(24, 144, 3, 2, 190), (32, 192, 3, 1, 95), (32, 192, 5, 2, 95)]
 r = np.random.default_rng(0)
 tele = Telemetry(0, hz=250.0, raw=True)
 for cin, c, k, s, Hh in shapes:
