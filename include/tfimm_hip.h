@@ -406,7 +406,8 @@ TFIMM_API int tfimm_hip_conv_chain(const tfimm_chain_desc* d, void* stream);
  *   b1, b2  fp32 [Cpad] folded BN shifts;  wdw  fp32 [k*k][Cpad] depthwise taps (BN scale folded), zero padded
  *   y    bf16 [B][OH][OW][C];  sum_out  int64 [B][C] fixed-point squeeze sums as in tfimm_hip_dwconv (zeroed by the caller) or NULL
  * k in {3, 5}, stride in {1, 2}, explicit top / left zero padding of the EXPANDED tensor (bottom / right follow from
- * OH, OW).  Anything else returns TFIMM_EUNSUP and the caller runs the two launches.
+ * OH, OW); at stride 1 at most 512 expanded channels (their bias is staged in LDS once); one image of the output below 2 GiB.
+ * Anything else returns TFIMM_EUNSUP and the caller runs the two launches.
  * ------------------------------------------------------------------------------------- */
 typedef struct tfimm_expand_dw_desc {
   const void* x;

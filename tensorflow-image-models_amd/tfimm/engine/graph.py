@@ -813,7 +813,7 @@ class Builder:
         kh, kw = kd.shape[:2]
         if (k1.shape[:2] != (1, 1) or x.C != cin or cin % 8 or cin > 32 or c % 2 or kd.shape[2:] != (c, 1) or kh != kw
                 or (kh, stride) not in ((3, 1), (3, 2), (5, 2)) or os.environ.get("TFIMM_NO_MBCONV_FUSION", "0") == "1"
-                or self.fp32):
+                or self.fp32 or (stride == 1 and c > 512)):        # (stride 1: the expansion bias of all chunks sits in 2 KiB of LDS)
             return None
         if padding == "same":
             OH, pt, _ = same_padding(x.H, kh, stride)
