@@ -348,6 +348,21 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       const int64_t ntiles = (int64_t)ga.g.tiles_m * ga.g.tiles_n;
       if (ntiles > 0x7fffffffLL) TFIMM_FAIL(TFIMM_EINVAL, "gemm: grid too large");
       ga.n_tiles = (int)ntiles;
+      {
+        // column-panel groups (GemmStreamArgs::ngroup).  TFIMM_GEMM_NGROUP: -1 (default) = the rule below, 0 = never, n = groups of n
+        static const int ng_env = getenv("TFIMM_GEMM_NGROUP") ? atoi(getenv("TFIMM_GEMM_NGROUP")) : -1;
+        int ng = 0;
+        if (ng_env > 0) ng = ng_env;
+        else if (ng_env < 0 && w_bytes > (int64_t)(3 << 20) && ga.g.tiles_m >= 64) {
+          // as many weight panels as stay in a 4-MiB L2 next to the streaming rows: 2.5 MB of them (ViT-B, K = 768, 256-column
+          // panels of 393 KB: groups of 6 -- measured -0.9 .. -1.1 % of a ViT-B step on three boxes; 5, 7, 8 and the half split
+          // of 9 panels gain 0.2 .. 0.6 %, groups of 2 LOSE 2 %: A is re-read once per group)
+          const int64_t panel = (int64_t)t->bn * d.ldw * 2;
+          ng = (int)((int64_t)2621440 / (panel > 0 ? panel : 1));
+          if (ng < 3) ng = 0;
+        }
+        ga.ngroup = (ng > 0 && ng < ga.g.tiles_n) ? ng : 0;
+      }
       ga.cin64 = (kmode == K_CONV && (d.Cin % (ti == 9 ? 32 : 64)) == 0) ? 1 : 0;   // whole k-tiles inside one filter tap
       ga.duo_delay = 0;
       ga.duo_first = num_cu() / 8;

@@ -53,6 +53,11 @@ struct GemmStreamArgs {
   const void* ln_c1;          // bf16 [N][2][8] correction fragments (pack.pack_ln_c1)
   unsigned ln_stats_bytes, ln_c1_bytes;
   // duo kernel (gemm_duo_kernel.h): workgroups with (blockIdx.x >> 3) >= duo_first start duo_delay cycles late
+  // tile order inside the list: 0 = M-panel-major (a row panel of A meets every weight panel before the next row panel starts);
+  // g > 0 = groups of g weight panels, each group swept over ALL row panels before the next group starts -- the group's weights
+  // (g x BN x K x 2 bytes) stay in the XCD's L2 while the rows stream by, at the price of reading A once per group.  Pays when
+  // the weight matrix does not fit in a 4-MiB L2 and is re-fetched per row panel (ViT-B fc1: 4.7 MB x 394 row panels).
+  int ngroup;
   int duo_delay, duo_first;
   long long* dbg_ptr; // TFIMM_GEMM_DBG_PTR: s_memtime stamps of workgroup 0 (dbg & 64)
   int dbg;           // TFIMM_GEMM_DBG: bit 64 = record the stamps (tools/gemm_stamps.py)
@@ -114,6 +119,19 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
     t_first = t_lo + j;
   }
   if (t_first >= t_hi) return;
+  // tile index -> (row panel, column panel): see GemmStreamArgs::ngroup
+  auto tile_mn = [&](int tile, int& mt, int& nt) __attribute__((always_inline)) {
+    if (pa.ngroup <= 0) {
+      mt = tile / p.tiles_n;
+      nt = tile - mt * p.tiles_n;
+    } else {
+      const int per_group = p.tiles_m * pa.ngroup;
+      const int g = tile / per_group, r = tile - g * per_group;
+      const int gw = min(pa.ngroup, p.tiles_n - g * pa.ngroup);      // the last group may be narrower
+      mt = r / gw;
+      nt = g * pa.ngroup + (r - mt * gw);
+    }
+  };
 
   const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(p.a, pa.a_bytes);
   const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(p.wt, pa.w_bytes);
@@ -146,7 +164,8 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   // `valid` false (no further tile for this workgroup): every offset out of range, the DMA that is
   // still issued unconditionally then only writes zeros -- keeps the K loop free of VMEM branches
   auto setup_issue = [&](int tile, bool valid) __attribute__((always_inline)) {
-    const int mt = tile / p.tiles_n, nt = tile - mt * p.tiles_n;
+    int mt, nt;
+    tile_mn(tile, mt, nt);
     const int m0 = mt * BM, n0 = nt * BN;
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) {
@@ -249,7 +268,8 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   // +256) of slot pi / ppr (ppr = pieces per slot); anything outside the table (k >= K, image >= B, pi beyond the
   // last slot) has an out-of-range offset and lands as zeros
   auto issue_scales = [&](int tile, bool valid, int buf) __attribute__((always_inline)) {
-    const int mt = tile / p.tiles_n;
+    int mt, nt_unused;
+    tile_mn(tile, mt, nt_unused);
     const int b0 = (mt * BM) / p.rows_per_image;
     const int ppr = pa.s_stride >> 8;
     for (int j = 0; j < pa.s_pieces; ++j) {
@@ -303,7 +323,8 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   };
 
   for (int tile = t_first; tile < t_hi; tile += t_step) {
-    const int mt = tile / p.tiles_n, nt = tile - mt * p.tiles_n;
+    int mt, nt;
+    tile_mn(tile, mt, nt);
     const int m0 = mt * BM, n0 = nt * BN;
     const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);
     const int e_n = n0 + wn * WTN + e_c8 * 8;        // first of this lane's 8 output channels
