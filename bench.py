@@ -23,6 +23,8 @@ Printed JSON (one line, rank 0): metric / value / unit / ... plus
                 margin explains,
   parity        top level: per model the rel-to-max error and the top-1 figures (bf16 random head / calibrated head /
                 float32 path) -- ResNet-50 AND ViT-B/16, the two models the metric names,
+  energy        joules per step (mean socket power of the sustained window x its time per step) against the floor this part's
+                energy per MFMA flop and per HBM byte set at its 1400-W cap,
   sclk_mhz_mean / power_w_mean / power_cap_w / telemetry / sustained
                 shader clock and socket power of this box over the timed region (side-thread samples of the amdsmi
                 gpu_metrics table, tfimm/utils/telemetry.py) and over >= 0.6 s of back-to-back replays; every workload
@@ -816,7 +818,7 @@ def main():
             "roofline": m["roofline"], "cpu_baseline": m.get("cpu_baseline"), "parity_vs_oracle": m.get("parity_vs_oracle"),
             "parity": parity_summary([(args.workload, m)] + list(also.items())),
             "sclk_mhz_mean": m.get("sclk_mhz_mean"), "power_w_mean": m.get("power_w_mean"), "power_cap_w": m.get("power_cap_w"),
-            "telemetry": m.get("telemetry"), "sustained": m.get("sustained"),
+            "telemetry": m.get("telemetry"), "sustained": m.get("sustained"), "energy": m.get("energy"),
             "headline": {k: (v["value"] if v and "value" in v else None)
                          for k, v in [(args.workload, m)] + list(also.items())},
             "also": also,
