@@ -65,3 +65,12 @@ def test_one_rank_through_the_launcher():
     assert line["n_gpus"] == 1 and line["config"]["launcher"] == "bench.py spawn"
     assert line["config"]["exchange"].startswith("RCCL") and line["config"]["launch"] == "hipGraph replay"
     assert line["value"] > 0 and len(line["per_rank_ms"]) == 1 and line["roofline"]["frac"] > 0
+    # round 5: clock / power of the box next to the number (the sampler is a child process; a box without any source says so)
+    for key in ("sclk_mhz_mean", "power_w_mean", "power_cap_w", "telemetry", "sustained", "energy", "parity"):
+        assert key in line, key
+    tl = line["telemetry"]
+    assert tl["source"] is not None or "error" in tl
+    if tl["source"] is not None:
+        assert 100 < line["sclk_mhz_mean"] < 3000 and 100 < line["power_w_mean"] <= 1.05 * line["power_cap_w"]
+        assert line["sustained"]["steps"] >= 3 and line["sustained"]["ms_per_step"] > 0
+    assert line["config"]["exchange_mode"].startswith("asynchronous")
