@@ -1020,9 +1020,12 @@ static int launch_dwconv_rows(const bf16_t* x, const float* w, const float* bias
   const int64_t gx = (int64_t)ctiles * sgroups * nseg;
   if (gx > 0x7fffffffLL) TFIMM_FAIL(TFIMM_EINVAL, "dwconv: grid too large");
   const size_t lds = (size_t)(K * K + 2) * CPB * sizeof(tfimm_f32x2);      // taps + 2 CPB fixed-point squeeze sums
-  // input rows in flight per thread: 2 measured slower than 1 (EfficientNet-B4 depthwise 4.68 -> 5.36 ms: the second buffer
-  // costs a wave per SIMD), TFIMM_DW_DEPTH=2 keeps it selectable for the swish flavour
-  static const int depth = getenv("TFIMM_DW_DEPTH") ? atoi(getenv("TFIMM_DW_DEPTH")) : 1;
+  // input rows in flight per thread.  Round 2: two measured slower than one (EfficientNet-B4 depthwise 4.68 -> 5.36 ms).  With the
+  // row loop's VMEM countable (round 5: the loop no longer drains its stores at every row) the second row pays for k = 5:
+  // 266 -> 256, 194 -> 183, 84.5 -> 81.4 us on the three k = 5 shapes of EfficientNet-B4, k = 3 unchanged (tools/dw_diag.py,
+  // interleaved on one box).  TFIMM_DW_DEPTH=1 / 2 forces either (swish flavour only).
+  static const int depth_env = getenv("TFIMM_DW_DEPTH") ? atoi(getenv("TFIMM_DW_DEPTH")) : 0;
+  const int depth = depth_env ? depth_env : (K == 5 ? 2 : 1);
   auto go = [&](auto kern) -> int {
     static tfimm_once_t attr_done;       // one flag set per kernel instantiation (generic lambda)
     if (attr_done.need()) {
