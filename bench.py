@@ -269,17 +269,14 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
 
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize()
+    tele.start()              # (sampler process: shader clock / socket power) -- started in front of the barrier, so that its
+    torch.cuda.synchronize()  # round trip is not idle GPU time between the warm-up and the first timed step
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]   # per-step durations for the median: events on
-    tele.start()                                                               # (side thread: shader clock / socket power)
-    t0 = time.perf_counter()                                                   # the launch stream, no host synchronisation
-    marks[0].record()
-    for i in range(steps):
+    t0 = time.perf_counter()
+    for i in range(steps):    # exactly K steps and nothing else between the two synchronisations
         step()
-        marks[i + 1].record()
     if pipe is not None:
         pipe.drain()                                       # the last steps' exchanges are inside the timed region
     torch.cuda.synchronize()
@@ -290,6 +287,16 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
     telemetry = tele.stop().summary()
     if pipe is not None:
         gathered = pipe.last()
+    # per-step durations for the median: the same K steps once more with an event on the launch stream between them -- a pass
+    # of its own (an event record between two graph launches costs a step of ResNet-50 about 50 us: it stays out of `value`)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    marks[0].record()
+    for i in range(steps):
+        step()
+        marks[i + 1].record()
+    if pipe is not None:
+        pipe.drain()
+    torch.cuda.synchronize()
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
     median_ms = per_step[steps // 2] if steps % 2 else 0.5 * (per_step[steps // 2 - 1] + per_step[steps // 2])
     # the exchange step really delivered this rank's logits (and, world = 1, nothing else): bit for bit
@@ -726,7 +733,10 @@ def run_workload(name, args, world, rank, dist, steps, warmup, batch=0, micro_ba
                    mfma_frac_whole_step=round(flops_img * batch / ms / 1e9 / 2500.0, 4),
                    # clock / power state of THIS box over the timed region (side-thread samples; energy_power_w = the firmware's
                    # energy accumulator over the same window) and over a sustained window of the same recording
-                   sclk_mhz_mean=r["telemetry"].get("sclk_mhz_mean"), power_w_mean=r["telemetry"].get("power_w_mean"),
+                   # (power: from the firmware's energy counter over the window when it is there -- the sampled socket power is a
+                   #  filtered value that lags by ~100 ms, far too slow for a 70-ms region; the samples stay in `telemetry`)
+                   sclk_mhz_mean=r["telemetry"].get("sclk_mhz_mean"),
+                   power_w_mean=r["telemetry"].get("energy_power_w") or r["telemetry"].get("power_w_mean"),
                    power_cap_w=r["telemetry"].get("power_cap_w"), telemetry=r["telemetry"], sustained=r["sustained"],
                    exchange_mode=r["exchange_mode"],
                    roofline=rl)
