@@ -42,6 +42,14 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tensorflow-image-models_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))       # telemetry.py: measurement tooling, not part of the product package
+
+# What is inside the timed region, by number (frozen since round 5; see README "bench protocol"):
+#   2 = K hipGraph replays (logits written by the recording's last node), the asynchronous double-buffered all-gather submitted per
+#       step and drained before the clock stops; per-step event records in a pass of their own.  (1 = rounds 1-4: an event record and
+#       a logits copy launch per step inside the region, the all-gather on the launch stream.)
+PROTOCOL_VERSION = 2
+LINE_LIMIT = 4096          # bytes of the ONE stdout line (the driver's parser lost round 5's 21-KB line); everything else -> detail file
 
 # BASELINE.json configs -> (model, per-GPU batch, roofline bound, kernel family the roofline is quoted on)
 #   mfma: achieved = FLOPs of the GEMM launches / their time
@@ -71,8 +79,8 @@ ALG_BYTES_PER_IMAGE = {"resnet50": 56.8e6, "swin_base_patch4_window7_224": 140.1
 # (flops x E_MFMA + algorithmic bytes x E_HBM) / (cap - idle): the `energy` object of a workload states that floor next to the
 # joules the step really took (mean socket power of the sustained window x its time per step).
 E_MFMA_PJ_PER_FLOP, E_HBM_NJ_PER_BYTE, P_IDLE_W = 0.62, 0.15, 255.0
-FAMILY_KERNELS = {"gemm": "tfimm_gemm::* (every GEMM / convolution flavour, incl. the fused bottleneck tail) + stem_pool_kernel",
-                  "attention": "attn_*_kernel", "dwconv": "dwconv_*_kernel + expand_dw_kernel (fused expansion + depthwise)"}
+FAMILY_KERNELS = {"gemm": "tfimm_gemm::* (all GEMM / conv flavours) + stem_pool_kernel",
+                  "attention": "attn_*_kernel", "dwconv": "dwconv_*_kernel + expand_dw_kernel"}
 
 
 def parse():
@@ -172,7 +180,7 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
     # communicator's stream under the kernels of step i + 1 (tfimm/engine/dp.py PipelinedGather); TFIMM_BENCH_SYNC_GATHER=1
     # issues it the round-4 way (on the launch stream, between two replays) for the A/B under profiles/
     from tfimm.engine.dp import PipelinedGather
-    from tfimm.utils.telemetry import Telemetry
+    from telemetry import Telemetry
     sync_gather = os.environ.get("TFIMM_BENCH_SYNC_GATHER") == "1"
     pipe = PipelinedGather(batch, out_t.C, torch.float32, "cuda", dist) if (dist is not None and not sync_gather) else None
     gathered = torch.empty(world * batch, out_t.C, dtype=torch.float32, device="cuda") if (dist is not None and sync_gather) else None
@@ -549,8 +557,7 @@ def cpu_baseline(model, name, target_seconds=20.0, parity_images=1024):
             fs.append(f)
     feats = None if (not poolable or any(f is None for f in fs)) else np.concatenate(fs)
     return (dict(value=round(b * n / dt, 2), unit="images/sec", cores=cores, kind="port",
-                 sample=f"{n} forwards of batch {b} ({name}, fp32 torch-CPU restatement of the reference's forward, pinned "
-                        f"to the reference's own code in tests/test_golden.py; TensorFlow itself is unavailable)"),
+                 sample=f"{n} forwards of batch {b}, {name}, fp32 torch-CPU oracle"),
             np.concatenate(xs), np.concatenate(ys), feats)
 
 
@@ -754,6 +761,110 @@ def run_workload(name, args, world, rank, dist, steps, warmup, batch=0, micro_ba
     return out
 
 
+def detail_record(args, m, also, world, distributed, launched):
+    """Everything the run measured (the round-5 line): goes to the detail file and stderr, never to stdout."""
+    return {
+        "metric": "images/sec (fwd, bf16)", "value": m["value"], "unit": "images/sec", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
+        "median_ms_per_step": m["median_ms_per_step"], "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "protocol_version": PROTOCOL_VERSION,
+        "config": {"workload": f"{m['model']} @{m['input_size']} fwd", "per_gpu_batch": m["per_gpu_batch"],
+                   "global_batch": m["global_batch"], "micro_batch": args.micro_batch or m["per_gpu_batch"],
+                   "parallelism": f"dp{world}", "exchange": ("none" if not distributed else "RCCL all-gather of fp32 logits" if args.backend == "nccl"
+                                else "gloo all-gather of fp32 logits (host)"),
+                   "exchange_mode": m.get("exchange_mode"),
+                   "ranks": world, "launcher": ("bench.py spawn" if os.environ.get("TFIMM_BENCH_SPAWNED") else
+                                                "external" if launched else "in-process"),
+                   "weights": "random-init (synthetic generator, seed 2021)", "launch": m["launch"],
+                   "branches": m["branches"], "single_branch_ms_per_step": m["single_branch_ms_per_step"],
+                   "forked_ms_per_step": m["forked_ms_per_step"], "gflops_per_image": m["gflops_per_image"],
+                   "forked_bit_equal_to_single": m["forked_bit_equal_to_single"],
+                   "gathered_logits_bit_equal_to_local": m["gather_bit_equal"]},
+        "per_rank_ms": m["per_rank_ms"], "model_tflops": m["model_tflops"],
+        "roofline": m["roofline"], "cpu_baseline": m.get("cpu_baseline"), "parity_vs_oracle": m.get("parity_vs_oracle"),
+        "parity": parity_summary([(args.workload, m)] + list(also.items())),
+        "sclk_mhz_mean": m.get("sclk_mhz_mean"), "power_w_mean": m.get("power_w_mean"), "power_cap_w": m.get("power_cap_w"),
+        "telemetry": m.get("telemetry"), "sustained": m.get("sustained"), "energy": m.get("energy"),
+        "headline": {k: (v["value"] if v and "value" in v else None)
+                     for k, v in [(args.workload, m)] + list(also.items())},
+        "also": also,
+    }
+
+
+_ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_step",
+                  "algorithmic_bytes_per_launch", "kernel", "launches_per_step", "avg_launch_ms", "frac_timed_mode")
+
+
+def _short(s, n):
+    return s if s is None or len(s) <= n else s[:n - 1] + "~"
+
+
+def _compact_roofline(rl):
+    if not rl:
+        return None
+    out = {k: rl.get(k) for k in _ROOFLINE_KEYS if k in rl}
+    out["kernel"] = _short(out.get("kernel"), 96)
+    return out
+
+
+def compact_line(d):
+    """The ONE stdout line: the contract's fields + roofline + cpu_baseline + one parity figure per model + the four headline
+    numbers, always below LINE_LIMIT bytes -- the optional groups are dropped last-first if a run ever grows past it."""
+    cfg = d["config"]
+    line = {k: d[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "median_ms_per_step",
+                              "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "protocol_version")}
+    line["config"] = {k: cfg[k] for k in ("workload", "per_gpu_batch", "global_batch", "parallelism", "exchange", "ranks",
+                                          "launcher", "launch", "branches")}
+    line["config"]["launch"] = _short(cfg["launch"], 120)
+    line["per_rank_ms"] = [round(float(v), 4) for v in d["per_rank_ms"]]
+    line["roofline"] = _compact_roofline(d.get("roofline"))
+    cb = d.get("cpu_baseline")
+    line["cpu_baseline"] = None if not cb else dict(value=cb["value"], unit=cb["unit"], cores=cb["cores"], kind=cb["kind"],
+                                                    sample=_short(cb.get("sample"), 72))
+    par = (d.get("parity") or {}).get("models") or {}
+    line["parity"] = {name: dict(images=p.get("images"), rel_to_max=_r(p.get("bf16_rel_to_max_err"), 5),
+                                 top1=_r(p.get("bf16_top1_match_random_head"), 4),
+                                 top1_calibrated_head=_r(p.get("bf16_top1_match_calibrated_head"), 4),
+                                 top1_fp32_path=_r(p.get("fp32_path_top1_match"), 4),
+                                 rel_to_max_fp32_path=_r(p.get("fp32_path_rel_to_max_err"), 8))
+                      for name, p in par.items()} or None
+    line["headline"] = d["headline"]
+    line["clock_power"] = dict(sclk_mhz_mean=d.get("sclk_mhz_mean"), power_w_mean=d.get("power_w_mean"), power_cap_w=d.get("power_cap_w"))
+    # the other BASELINE configurations: value / time / roofline fraction each (their full objects are in the detail file)
+    line["also"] = {}
+    for name, v in (d.get("also") or {}).items():
+        if not v or "value" not in v:
+            line["also"][name] = {"error": _short((v or {}).get("error", "no result"), 80)}
+            continue
+        rl = v.get("roofline") or {}
+        line["also"][name] = dict(value=v["value"], ms_per_step=v["ms_per_step"], per_gpu_batch=v["per_gpu_batch"], branches=v.get("branches"),
+                                  bound=rl.get("bound"), frac=rl.get("frac"), achieved=rl.get("achieved"), unit=rl.get("unit"))
+    line["detail"] = "bench_detail.json (+ stderr)"
+    for drop in (None, "clock_power", "also", "parity"):
+        if drop is not None:
+            line.pop(drop, None)
+        text = json.dumps(line, separators=(",", ":"))
+        if len(text) < LINE_LIMIT:
+            return text
+    raise RuntimeError(f"bench line is {len(text)} bytes even without its optional groups (limit {LINE_LIMIT})")
+
+
+def _r(v, n):
+    return None if v is None else round(float(v), n)
+
+
+def write_detail(detail):
+    """The full record: bench_detail.json next to bench.py (or $TFIMM_BENCH_DETAIL) and, as one line, on stderr."""
+    text = json.dumps(detail)
+    print("bench detail: " + text, file=sys.stderr)
+    path = os.environ.get("TFIMM_BENCH_DETAIL") or os.path.join(ROOT, "bench_detail.json")
+    try:
+        with open(path, "w") as f:
+            f.write(text + "\n")
+    except OSError as e:
+        print(f"warning: could not write {path}: {e}", file=sys.stderr)
+
+
 def main():
     args = parse()
     launched = "WORLD_SIZE" in os.environ
@@ -798,43 +909,20 @@ def main():
             # the metric names ViT-B/16 next to ResNet-50: it gets the full protocol (K steps, W warm-ups) and, on one GPU, its own
             # CPU baseline and parity statement (bounded: ~6 s of CPU, >= 64 images); the other configurations half the steps
             vit = name == "vit_base_patch16_224"
+            # (every BASELINE configuration carries parity next to its throughput: 128 images each on one GPU)
             also[name] = run_workload(name, args, world, rank, dist, args.steps if vit else max(3, args.steps // 2),
                                       args.warmup if vit else max(2, args.warmup // 2),
-                                      with_cpu=(vit and world == 1 and not args.no_cpu_baseline), cpu_seconds=6.0, parity_images=128)
+                                      with_cpu=(world == 1 and not args.no_cpu_baseline), cpu_seconds=6.0, parity_images=128)
         except Exception as e:  # noqa: BLE001
             if dist is not None:
                 raise                     # a rank that skips a collective would hang the others
             also[name] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
-        m = main_r
-        line = {
-            "metric": "images/sec (fwd, bf16)", "value": m["value"], "unit": "images/sec", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
-            "median_ms_per_step": m["median_ms_per_step"], "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{m['model']} @{m['input_size']} fwd", "per_gpu_batch": m["per_gpu_batch"],
-                       "global_batch": m["global_batch"], "micro_batch": args.micro_batch or m["per_gpu_batch"],
-                       "parallelism": f"dp{world}", "exchange": ("none" if dist is None else "RCCL all-gather of fp32 logits" if args.backend == "nccl"
-                                    else "gloo all-gather of fp32 logits (host)"),
-                       "exchange_mode": m.get("exchange_mode"),
-                       "ranks": world, "launcher": ("bench.py spawn" if os.environ.get("TFIMM_BENCH_SPAWNED") else
-                                                    "external" if launched else "in-process"),
-                       "weights": "random-init (synthetic generator, seed 2021)", "launch": m["launch"],
-                       "branches": m["branches"], "single_branch_ms_per_step": m["single_branch_ms_per_step"],
-                       "forked_ms_per_step": m["forked_ms_per_step"], "gflops_per_image": m["gflops_per_image"],
-                       "forked_bit_equal_to_single": m["forked_bit_equal_to_single"],
-                       "gathered_logits_bit_equal_to_local": m["gather_bit_equal"]},
-            "per_rank_ms": m["per_rank_ms"], "model_tflops": m["model_tflops"],
-            "roofline": m["roofline"], "cpu_baseline": m.get("cpu_baseline"), "parity_vs_oracle": m.get("parity_vs_oracle"),
-            "parity": parity_summary([(args.workload, m)] + list(also.items())),
-            "sclk_mhz_mean": m.get("sclk_mhz_mean"), "power_w_mean": m.get("power_w_mean"), "power_cap_w": m.get("power_cap_w"),
-            "telemetry": m.get("telemetry"), "sustained": m.get("sustained"), "energy": m.get("energy"),
-            "headline": {k: (v["value"] if v and "value" in v else None)
-                         for k, v in [(args.workload, m)] + list(also.items())},
-            "also": also,
-        }
+        detail = detail_record(args, main_r, also, world, dist is not None, launched)
+        line = compact_line(detail)
+        write_detail(detail)
         sys.stdout.flush()
-        os.write(saved_stdout, (json.dumps(line) + "\n").encode())
+        os.write(saved_stdout, (line + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

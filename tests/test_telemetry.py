@@ -1,7 +1,11 @@
-"""CPU: the clock / power telemetry of bench.py (tfimm/utils/telemetry.py) on a scripted source, and the no-source case."""
+"""CPU: the clock / power telemetry of bench.py (tools/telemetry.py -- measurement tooling, not part of the product package)
+on a scripted source, the no-source case, and a sampler child that stops answering."""
+import os
+import sys
 import time
 
-from tfimm.utils.telemetry import Telemetry, open_source
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+from telemetry import Telemetry, open_source  # noqa: E402
 
 
 class _Scripted:
@@ -59,3 +63,26 @@ def test_not_available_fields_do_not_poison_the_means():
         time.sleep(0.05)
     s = t.summary()
     assert s["power_w_mean"] is not None and s["sclk_mhz_mean"] is not None and "energy_power_w" not in s
+
+
+def test_a_child_that_misses_an_answer_is_dropped_for_every_instance(monkeypatch):
+    """The sampler child is shared per device; one that timed out must not hand its late reply to the next instance."""
+    class Mute:
+        closed = 0
+
+        def ask(self, cmd, timeout=5.0):
+            return None
+
+        def cap(self):
+            return None
+
+        def close(self):
+            Mute.closed += 1
+
+    key = ("child", 0, 200.0)
+    monkeypatch.setitem(Telemetry._shared, key, (Mute(), []))
+    t = Telemetry(0)
+    assert t.child is Telemetry._shared[key][0]
+    t.start()
+    assert t.child is None and key not in Telemetry._shared and Mute.closed == 1
+    assert t.stop().summary()["source"] is None

@@ -6,7 +6,7 @@ for p in (ROOT, os.path.join(ROOT, "tensorflow-image-models_amd"), os.path.join(
     sys.path.insert(0, p)
 import torch
 import hip_ops as H
-from tfimm.utils.telemetry import Telemetry
+from telemetry import Telemetry
 
 shapes = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [(336, 48, 5, 1), (672, 24, 3, 1), (960, 24, 5, 1), (1632, 12, 5, 1), (2688, 12, 3, 1)]
 B = 256

@@ -26,7 +26,7 @@ dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.dev
 import bench
 from tfimm.engine.dp import PipelinedGather
 from tfimm.engine.graph import CapturedHybrid
-from tfimm.utils.telemetry import Telemetry
+from telemetry import Telemetry
 
 model = bench.build_model(name)
 x = bench.synthetic_batch(model.cfg, batch, 2021 + rank)

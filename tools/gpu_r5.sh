@@ -21,7 +21,7 @@ import sys, json, time, glob, os
 sys.path.insert(0, "$R/tensorflow-image-models_amd")
 import torch
 torch.cuda.init(); x = torch.zeros(1, device="cuda")
-from tfimm.utils import telemetry as T
+import telemetry as T
 print("bus id of cuda:0:", T.torch_bus_id(0))
 for cls in (T._AmdSmiSource, T._HwmonSource, T._RocmSmiSource):
     t = time.time()

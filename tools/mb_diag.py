@@ -8,7 +8,7 @@ import numpy as np
 import torch
 import hip_ops as H
 from tfimm.engine import pack
-from tfimm.utils.telemetry import Telemetry
+from telemetry import Telemetry
 
 B = int(os.environ.get("MB_BATCH", "256"))
 shapes = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [(24, 144, 3, 2, 190), (32, 192, 3, 1, 95), (32, 192, 5, 2, 95)]

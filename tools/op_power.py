@@ -27,7 +27,7 @@ def main():
     import test_architectures  # noqa: F401
     import tfimm
     from tfimm.utils.init import synthetic_weights
-    from tfimm.utils.telemetry import Telemetry
+    from telemetry import Telemetry
     defaults = {"resnet50": 256, "vit_base_patch16_224": 512, "swin_base_patch4_window7_224": 256, "efficientnet_b4": 256}
     B = int(sys.argv[2]) if len(sys.argv) > 2 else defaults.get(name, 64)
     win = float(sys.argv[3]) if len(sys.argv) > 3 else 0.3

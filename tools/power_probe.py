@@ -42,7 +42,7 @@ def window(samples, t0, t1, skip=0.15):
 def main():
     sustain_ms = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
     import torch
-    from tfimm.utils.telemetry import Telemetry
+    from telemetry import Telemetry
     torch.cuda.init()
     tele = Telemetry(0, hz=250.0, raw=True)
     rows = []

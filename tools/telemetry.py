@@ -332,21 +332,30 @@ class Telemetry:
         self.t0 = time.perf_counter()
         if self.child is not None:
             if self.child.ask("start") is None:           # the sampler died: keep measuring without it
-                self.why = ["the sampler process stopped answering"]
-                self.child = self.src = None
+                self._drop_child()
             return self
         if self.src is not None:
             self._thread = threading.Thread(target=self._loop, name="tfimm-telemetry", daemon=True)
             self._thread.start()
         return self
 
+    def _drop_child(self):
+        """A sampler that missed an answer is closed and forgotten by EVERY instance: its late reply would otherwise be read as
+        the answer to the next instance's command (the child is shared per device through ``_shared``)."""
+        child = self.child
+        for key in [k for k, v in Telemetry._shared.items() if v[0] is child]:
+            del Telemetry._shared[key]
+        if child is not None:
+            child.close()
+        self.why = ["the sampler process stopped answering"]
+        self.child = self.src = None
+
     def stop(self):
         self.t1 = time.perf_counter()
         if self.child is not None:
             ans = self.child.ask("stop_raw" if self.raw else "stop", timeout=10.0)
             if not ans or "summary" not in ans:
-                self.why = ["the sampler process stopped answering"]
-                self.child = self.src = None
+                self._drop_child()
             else:
                 self._summary = ans["summary"]
                 self.samples = ans.get("samples", [])
