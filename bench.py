@@ -814,7 +814,7 @@ def compact_line(d):
     line = {k: d[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "median_ms_per_step",
                               "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "protocol_version")}
     line["config"] = {k: cfg[k] for k in ("workload", "per_gpu_batch", "global_batch", "parallelism", "exchange", "ranks",
-                                          "launcher", "launch", "branches")}
+                                          "launcher", "launch", "branches", "gathered_logits_bit_equal_to_local")}
     line["config"]["launch"] = _short(cfg["launch"], 120)
     line["per_rank_ms"] = [round(float(v), 4) for v in d["per_rank_ms"]]
     line["roofline"] = _compact_roofline(d.get("roofline"))

@@ -389,7 +389,7 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       grid = (grid + 7) / 8 * 8;
       const int64_t need = (ntiles + 7) / 8 * 8;
       if (grid > need) grid = need;
-      ga.s_bytes = 0; ga.s_slots = ga.s_stride = ga.s_pieces = 0;
+      ga.s_bytes = 0; ga.s_slots = ga.s_gp = 0;
       ga.ln_stats = d.ln_stats; ga.ln_c1 = d.ln_c1;
       ga.ln_stats_bytes = ln_in ? (unsigned)((int64_t)d.M * 8) : 0u;
       ga.ln_c1_bytes = ln_in ? (unsigned)((int64_t)d.N * 32) : 0u;
@@ -413,21 +413,21 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
         TFIMM_LAUNCH(t->fn[fi][ei], dim3((unsigned)grid), dim3(t->threads), (size_t)t->lds_bytes, (hipStream_t)stream, ga);
         return 0;
       }
-      // SE gate on A: the gate rows of the images a tile touches ride in LDS next to the operand ring (two buffers)
+      // SE gate on A: per k-tile, 64 gate values of every image a row tile touches ride in LDS next to the operand stage
+      // (1 KiB per four image slots and stage; wave w brings piece w)
       const int nw = t->threads / 64;
       const int64_t nimg = cdiv64(d.M, d.rows_per_image);
       ga.s_bytes = (unsigned)(nimg * d.K * 4);
       ga.s_slots = (int)cdiv64(t->bm, d.rows_per_image) + 1;
-      ga.s_stride = (int)(cdiv64(d.K, 256) * 256);
-      ga.s_pieces = (int)cdiv64((int64_t)ga.s_slots * (ga.s_stride / 256), nw);
-      const size_t lds = (size_t)t->lds_bytes + (size_t)2 * ga.s_pieces * nw * 1024;
-      if (lds <= 160 * 1024 && nimg * d.K * 4 <= 0x7fffff00LL) {
+      ga.s_gp = (ga.s_slots + 3) / 4;
+      const size_t lds = (size_t)t->lds_bytes + (size_t)2 * ga.s_gp * 1024;
+      if (ga.s_gp <= nw && lds <= 160 * 1024 && nimg * d.K * 4 <= 0x7fffff00LL) {
         static tfimm_once_t scale_attr[TFIMM_GEMM_STREAM_NUM_TILES][3];
         if (scale_attr[ti][ei].need()) {
           TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)t->fn_scale[ei], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
           scale_attr[ti][ei].mark();
         }
-        // resident workgroups per CU with the gate buffers counted in
+        // resident workgroups per CU with the gate slices counted in
         int occ_s = (int)((160 * 1024) / lds);
         occ_s = occ_s < 1 ? 1 : (occ_s > occ_f[ti] ? occ_f[ti] : occ_s);
         grid = ((int64_t)num_cu() * occ_s + 7) / 8 * 8;
@@ -435,7 +435,7 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
         TFIMM_LAUNCH(t->fn_scale[ei], dim3((unsigned)grid), dim3(t->threads), lds, (hipStream_t)stream, ga);
         return 0;
       }
-      // does not fit: the register-staged kernel below
+      // more image slots per tile than waves to bring them (images of a few rows): the register-staged kernel below
     }
   }
 

@@ -42,12 +42,11 @@ struct GemmStreamArgs {
   int n_tiles;       // tiles_m * tiles_n
   int cin64;         // K_CONV: Cin % 64 == 0 (scalar tap stepping)
   unsigned cin_magic, kw_magic;   // K_CONV otherwise: floor(2^32 / d) + 1 for d = Cin, KW (0: K >= 65536, divide)
-  // SCALE flavour (SE gate on the A operand, a_scale[image][k]): gate rows of the images a tile touches are
-  // brought into LDS by the same DMA stream as the operands
+  // SCALE flavour (SE gate on the A operand, a_scale[image][k]): the gate values of one k-tile -- 64 floats for each image a row
+  // tile touches -- ride in LDS next to the operand stage of that k-tile, brought by the same DMA stream as the operands
   unsigned s_bytes;   // extent of the gate table
   int s_slots;        // image slots per tile: ceil(BM / rows_per_image) + 1
-  int s_stride;       // floats per slot (K rounded up to whole 1-KiB DMA pieces)
-  int s_pieces;       // DMA pieces per wave and tile (slots * stride / 256 / waves, rounded up)
+  int s_gp;           // 1-KiB DMA pieces per k-tile: ceil(s_slots / 4) (four slots of 256 bytes each), one per wave 0 .. s_gp-1
   // LNIN flavour (LayerNorm folded into this GEMM): per-row (mean, rstd) and the split column sums of the gamma-scaled weights
   const float* ln_stats;      // fp32 [M][2]
   const void* ln_c1;          // bf16 [N][2][8] correction fragments (pack.pack_ln_c1)
@@ -142,9 +141,9 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   // LNIN: this wave's private LDS block behind the operand ring: 1 KiB of (mean, rstd) pairs for 128 rows, then TN x 1 KiB
   // of correction fragments (one 16-byte fragment per lane and 32-column block)
   char* const lnw = smem + G::LDS_BYTES + wave * (1 + TN) * 1024;
-  // gate region: two buffers (tile being multiplied / tile being issued) of s_pieces * NW pieces of 256 floats
-  float* const sS = reinterpret_cast<float*>(smem + G::LDS_BYTES);
-  const int s_buf_floats = SCALE ? pa.s_pieces * NW * 256 : 0;
+  // gate region behind the operand ring: for each of the two stages s_gp KiB, slot j of a k-tile at byte j * 256
+  char* const sS = smem + G::LDS_BYTES;
+  const int s_gbytes = SCALE ? pa.s_gp * 1024 : 0;
 
   const int nk = (p.K + BK - 1) / BK;
   const int lrow = lane >> 3;   // row within an 8-row DMA piece
@@ -155,6 +154,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   int a_iy0[A_INSTR], a_ix0[A_INSTR], a_pix[A_INSTR];
   unsigned b_off[B_INSTR];
   int s_ky = 0, s_kx = 0, s_ci0 = 0;   // K_CONV + cin64: wave-uniform tap state of the next k-tile
+  int s_b0 = 0;                        // SCALE: first image of the tile being issued (-1: no tile)
 
   auto a_chunk = [&](int j) -> int {    // logical 16-byte k-chunk this lane fetches for DMA piece j
     const int r = (wave * A_INSTR + j) * 8 + lrow;
@@ -207,6 +207,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
       b_off[j] = (valid && n < p.N) ? (unsigned)(((size_t)nsrc * p.ldw + chunk * 8) * 2) : kOobOffset;
     }
     s_ky = s_kx = s_ci0 = 0;
+    if (SCALE) s_b0 = valid ? m0 / p.rows_per_image : -1;
   };
 
   // One 1-KiB DMA piece of the step being issued: pieces [0, B_INSTR) are this wave's weight rows,
@@ -264,28 +265,23 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
       }
     }
   };
-  // gate rows of the images tile `tile` touches -> gate buffer `buf`.  Piece pi covers floats [256 (pi % ppr),
-  // +256) of slot pi / ppr (ppr = pieces per slot); anything outside the table (k >= K, image >= B, pi beyond the
-  // last slot) has an out-of-range offset and lands as zeros
-  auto issue_scales = [&](int tile, bool valid, int buf) __attribute__((always_inline)) {
-    int mt, nt_unused;
-    tile_mn(tile, mt, nt_unused);
-    const int b0 = (mt * BM) / p.rows_per_image;
-    const int ppr = pa.s_stride >> 8;
-    for (int j = 0; j < pa.s_pieces; ++j) {
-      const int pi = wave + j * NW;
-      const int slot = pi / ppr, q = pi - slot * ppr;
-      const int k = q * 256 + lane * 4;
-      const int img = b0 + slot;
-      const bool ok = valid && slot < pa.s_slots && k < p.K && (int64_t)img * p.rows_per_image < p.M;
+  // gate values of k-tile `kt` of the tile being issued -> gate slice of `stage`: wave w < s_gp brings slots 4 w .. 4 w + 3,
+  // lane l the floats [4 (l % 16), +4) of slot 4 w + l / 16.  Anything outside the table (k >= K, image >= B, slot >= s_slots,
+  // no tile) has an out-of-range offset and lands as zeros.
+  auto issue_gate = [&](int kt, int stage) __attribute__((always_inline)) {
+    if (wave < pa.s_gp) {
+      const int slot = wave * 4 + (lane >> 4);
+      const int k = kt * BK + (lane & 15) * 4;
+      const int img = s_b0 + slot;
+      const bool ok = s_b0 >= 0 && slot < pa.s_slots && k < p.K && (int64_t)img * p.rows_per_image < p.M;
       const unsigned off = ok ? (unsigned)(((size_t)img * p.K + k) * 4) : kOobOffset;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_s, (lds_ptr_t)(sS + buf * s_buf_floats + pi * 256), 16, (int)off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_s, (lds_ptr_t)(sS + stage * s_gbytes + wave * 1024), 16, (int)off, 0, 0, 0);
     }
   };
-  int s_iss = 0;   // gate buffer the next issued tile writes
   auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < N_PIECES; ++q) issue_piece(q, kt, stage);
+    if (SCALE) issue_gate(kt, stage);
     issue_done();
   };
 
@@ -312,10 +308,8 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   // ---- prime the pipeline
   int iss_tile = t_first, iss_kt = 1;
   setup_issue(iss_tile, true);
-  if (SCALE) { issue_scales(iss_tile, true, s_iss); s_iss ^= 1; }
   issue(0, 0);
   int cur = 0;
-  int s_cmp = 0;   // gate buffer of the tile being multiplied
   bool stores_pending = false;   // the previous step ended an interior tile: its stores may still be in flight
   int stamp_i = 0;
   auto stamp = [&]() __attribute__((always_inline)) {
@@ -399,19 +393,32 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
       rres[it] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, (int)off, 0, 0));
     };
 
-    // SCALE: LDS offset (floats) of the gate row of each fragment row's image, relative to the tile's first image
-    const float* s_cur = sS + s_cmp * s_buf_floats;
-    int s_off[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) s_off[i] = 0;
+    // SCALE: the gate is applied to the A tile IN LDS, once per element and k-tile, by all waves together between the barrier that
+    // publishes the stage and a second one in front of the fragment reads (kstep).  (Rounds 1-5 scaled the FRAGMENTS in
+    // registers: every wave column repeated the work on the same rows -- four times in the 256 x 256 tile -- 20 VALU operations
+    // and 32 bytes of gate reads per 16-byte fragment inside the MFMA loop, which made the SE projections of EfficientNet
+    // VALU-bound at ~320 TFLOP/s; and hipcc, seeing plain LDS reads of the gate region next to LDS-DMA writes it could not tell
+    // apart, drained the prefetch of the next k-tile with vmcnt(0) right behind its issue.)
+    // A thread owns SC_IT 16-byte chunks of the tile: physical chunk index it * NT + tid; its row's gate slot and the chunk's
+    // first k inside a k-tile are fixed for the whole tile.  The gate values themselves arrive per k-tile (issue_gate): 1 KiB per
+    // four image slots and stage instead of whole gate rows per tile, so every tile shape fits in LDS whatever K is (rounds 1-5:
+    // two buffers of slots x K floats -- 43 KB for K = 1632 at 12 x 12 pixels -- sent EfficientNet-B4's last two stages to the
+    // register-staged kernel).
+    constexpr int NT = NW * 64;
+    constexpr int SC_IT = BM * 8 / NT;
+    static_assert(!SCALE || (SC_IT >= 1 && SC_IT * NT == BM * 8), "scale pass: whole chunks per thread");
+    unsigned sc_goff[SCALE ? SC_IT : 1];       // byte offset into a k-tile's gate slice: (image slot) * 256 + 4 * first k of the chunk
     if (SCALE) {
       const int b0 = m0 / p.rows_per_image;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * WTM + i * 32 + frow;
-        s_off[i] = ((m < p.M ? m : p.M - 1) / p.rows_per_image - b0) * pa.s_stride;
+      for (int it = 0; it < SC_IT; ++it) {
+        const int idx = it * NT + tid, row = idx >> 3;
+        const int chunk = (idx & 7) ^ ((row >> 1) & 7);             // logical k-chunk behind this physical slot (lds_slot)
+        const int m = m0 + row;
+        sc_goff[it] = (unsigned)(((m < p.M ? m : p.M - 1) / p.rows_per_image - b0) * 256 + chunk * 32);
       }
     }
+    const unsigned sc_gbase = (unsigned)(size_t)(lds_ptr_t)sS;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -449,10 +456,47 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
         iss_tile += t_step;
         iss_kt = 0;
         setup_issue(iss_tile, iss_tile < t_hi);
-        if (SCALE) { issue_scales(iss_tile, iss_tile < t_hi, s_iss); s_iss ^= 1; }
       }
       issue(iss_kt, cur ^ 1);
       ++iss_kt;
+
+      if (SCALE) {
+        // a[m][k] * gate[image(m)][k], rounded to bf16 once, written back in place.  Explicit ds_* instructions: the DMA
+        // just issued stays in flight (see above).  Two chunks at a time keep the pass inside the register budget.
+        const unsigned sa_addr = (unsigned)(size_t)(lds_ptr_t)(smem + cur * STAGE) + (unsigned)tid * 16u;
+        const unsigned gk = sc_gbase + (unsigned)(cur * s_gbytes);
+        constexpr int PAIR = SC_IT >= 2 ? 2 : 1;
+#pragma unroll
+        for (int it0 = 0; it0 < SC_IT; it0 += PAIR) {
+          u32x4 av[PAIR];
+          f32x4 g0[PAIR], g1[PAIR];
+          // reads and their wait in ONE asm statement: the outputs of an asm are "ready" for hipcc the moment the statement
+          // ends, a separate s_waitcnt statement does not hold back the arithmetic on them
+          const unsigned aa0 = sa_addr + (unsigned)(it0 * NT * 16), ga0 = gk + sc_goff[it0];
+          if (PAIR == 2) {
+            const unsigned aa1 = sa_addr + (unsigned)((it0 + PAIR - 1) * NT * 16), ga1 = gk + sc_goff[it0 + PAIR - 1];
+            asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %7 offset:16\n\t"
+                         "ds_read_b128 %3, %8\n\tds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(av[0]), "=&v"(g0[0]), "=&v"(g1[0]), "=&v"(av[PAIR - 1]), "=&v"(g0[PAIR - 1]), "=&v"(g1[PAIR - 1])
+                         : "v"(aa0), "v"(ga0), "v"(aa1), "v"(ga1) : "memory");
+          } else {
+            asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %4\n\tds_read_b128 %2, %4 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(av[0]), "=&v"(g0[0]), "=&v"(g1[0]) : "v"(aa0), "v"(ga0) : "memory");
+          }
+#pragma unroll
+          for (int u = 0; u < PAIR; ++u) {
+            tfimm_f32x2 v[4];
+            unpack8p(make_uint4(av[u][0], av[u][1], av[u][2], av[u][3]), v);
+            v[0] *= tfimm_f32x2{g0[u][0], g0[u][1]}; v[1] *= tfimm_f32x2{g0[u][2], g0[u][3]};
+            v[2] *= tfimm_f32x2{g1[u][0], g1[u][1]}; v[3] *= tfimm_f32x2{g1[u][2], g1[u][3]};
+            const uint4 o = pack8p(v);
+            const u32x4 ov = {o.x, o.y, o.z, o.w};
+            const unsigned aa = sa_addr + (unsigned)((it0 + u) * NT * 16);
+            asm volatile("ds_write_b128 %0, %1" ::"v"(aa), "v"(ov) : "memory");
+          }
+        }
+        tfimm_lds_reuse_barrier();        // every wave's scaled chunks are in LDS (lgkmcnt(0) + s_barrier)
+      }
 
       const uint4* sA = reinterpret_cast<const uint4*>(smem + cur * STAGE);
       const uint4* sB = reinterpret_cast<const uint4*>(smem + cur * STAGE + A_BYTES);
@@ -465,20 +509,6 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           fb[j] = __builtin_bit_cast(bf16x8, sB[lds_slot(wn * WTN + j * 32 + frow, ks * 2 + fhi)]);
-        if (SCALE) {
-          // a[m][k] * gate[image(m)][k] on the fragment (8 consecutive k of one row per lane), rounded to bf16 once
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            const float4* gp = reinterpret_cast<const float4*>(s_cur + s_off[i] + kt_cur * BK + ks * 16 + fhi * 8);
-            const float4 g0 = gp[0], g1 = gp[1];
-            const uint4 u = __builtin_bit_cast(uint4, fa[i]);
-            tfimm_f32x2 v[4];
-            unpack8p(u, v);
-            v[0] *= tfimm_f32x2{g0.x, g0.y}; v[1] *= tfimm_f32x2{g0.z, g0.w};
-            v[2] *= tfimm_f32x2{g1.x, g1.y}; v[3] *= tfimm_f32x2{g1.z, g1.w};
-            fa[i] = __builtin_bit_cast(bf16x8, pack8p(v));
-          }
-        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -491,7 +521,6 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
     stamp();
     for (int kt = 0; kt + 1 < nk; ++kt) kstep(false, kt);
     kstep(true, nk - 1);
-    s_cmp ^= 1;
     stamp();
 
     // ---- epilogue (per wave).  Aliased staging lives in the stage consumed last (index cur^1 now):

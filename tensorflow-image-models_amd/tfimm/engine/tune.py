@@ -16,7 +16,8 @@ persistent LDS-DMA tiles (ids: 256x256, 256x128, 128x128, 256x64, 128x64, 128x25
 import json
 import os
 
-_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tune.json")
+# TFIMM_GEMM_TUNE: another table file (A/B of two library builds, each with the table tuned for it: tools/ab_lib.sh)
+_PATH = os.environ.get("TFIMM_GEMM_TUNE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tune.json")
 CANDIDATES = (0, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 11, 12, 13, 14, 15, 16)
 # a layer with a folded LayerNormalization runs on the persistent tiles only (the library ignores any other hint for it)
 LN_CANDIDATES = (0, 21, 22, 23, 24, 25, 26, 27, 29, 30)
