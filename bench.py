@@ -162,6 +162,9 @@ def synthetic_batch(cfg, batch, seed):
     return ((x - mean) / std).to(torch.bfloat16).contiguous()
 
 
+_CAPI = {}     # the C-ABI communicator of this process (one per run: RCCL communicators are not cheap)
+
+
 def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist, graph=True, branches="auto"):
     """Timed region: barrier + sync, K steps, sync + barrier.  Returns seconds, per-kind kernel time, handles."""
     import torch
@@ -182,7 +185,13 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
     from tfimm.engine.dp import PipelinedGather
     from telemetry import Telemetry
     sync_gather = os.environ.get("TFIMM_BENCH_SYNC_GATHER") == "1"
-    pipe = PipelinedGather(batch, out_t.C, torch.float32, "cuda", dist) if (dist is not None and not sync_gather) else None
+    # TFIMM_DP_EXCHANGE=capi: the same pipelined exchange, the collective issued through the C ABI (include/tfimm_hip_dp.h:
+    # a direct ncclAllGather call site, tfimm/engine/dp.py CapiComm) instead of torch.distributed -- opt-in
+    comm = None
+    if dist is not None and not sync_gather and os.environ.get("TFIMM_DP_EXCHANGE") == "capi" and dist.get_backend() == "nccl":
+        from tfimm.engine.dp import CapiComm
+        comm = _CAPI.get("comm") or _CAPI.setdefault("comm", CapiComm(dist))
+    pipe = PipelinedGather(batch, out_t.C, torch.float32, "cuda", dist, comm=comm) if (dist is not None and not sync_gather) else None
     gathered = torch.empty(world * batch, out_t.C, dtype=torch.float32, device="cuda") if (dist is not None and sync_gather) else None
     tele = Telemetry(torch.cuda.current_device())
 
@@ -358,7 +367,8 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
     return dict(seconds=dt, ms_per_step=dt / steps * 1e3, median_ms_per_step=median_ms, gather_bit_equal=gather_bit_equal,
                 forked_bit_equal=forked_bit_equal, kernels=stats, logits=logits, x=x, prog=prog, telemetry=telemetry,
                 sustained=sustained, exchange_mode=(None if dist is None else "synchronous on the launch stream" if pipe is None else
-                                                    "asynchronous, double-buffered (dp.PipelinedGather): step i's all-gather under step i + 1"),
+                                                    "asynchronous, double-buffered (dp.PipelinedGather): step i's all-gather under step i + 1"
+                                                    + (", ncclAllGather through the C ABI (tfimm_hip_dp_all_gather_logits)" if comm is not None else "")),
                 graph=captured is not None, gathered=gathered, branches=(n_br if forked is not None else 1),
                 hybrid_cut=(hybrid_cut if forked is not None and hybrid_cut is not None and getattr(forked, "cut_op", None) == hybrid_cut else None),
                 n_ops=len(prog.ops),

@@ -191,6 +191,34 @@ def _load():
 lib = _load()
 
 
+_dp_lib = None
+
+
+def dp_lib():
+    """libtfimm_hip_dp.so (include/tfimm_hip_dp.h: the data-parallel exchange behind a C ABI), loaded on first use -- it
+    links RCCL, which a single-GPU forward never needs."""
+    global _dp_lib
+    if _dp_lib is None:
+        path = os.environ.get("TFIMM_HIP_DP_LIB") or os.path.join(_HERE, "libtfimm_hip_dp.so")
+        if not os.path.exists(path):
+            raise HipError(f"{path} not found: build it with `make -C tensorflow-image-models_amd/csrc`")
+        L = C.CDLL(path)
+        L.tfimm_hip_dp_abi_version.restype = C.c_int
+        L.tfimm_hip_dp_last_error.restype = C.c_char_p
+        L.tfimm_hip_dp_shard_bounds.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.tfimm_hip_dp_unique_id.argtypes = [C.c_void_p, C.c_size_t]
+        L.tfimm_hip_dp_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]
+        L.tfimm_hip_dp_world.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.tfimm_hip_dp_all_gather_logits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.tfimm_hip_dp_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.tfimm_hip_dp_destroy.argtypes = [C.c_void_p]
+        for f in ("shard_bounds", "unique_id", "create", "world", "all_gather_logits", "forward", "destroy"):
+            getattr(L, "tfimm_hip_dp_" + f).restype = C.c_int
+        assert L.tfimm_hip_dp_abi_version() == 1
+        _dp_lib = L
+    return _dp_lib
+
+
 def check(rc: int, what: str = ""):
     if rc != 0:
         msg = lib.tfimm_hip_last_error().decode("utf-8", "replace")

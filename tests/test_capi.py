@@ -131,3 +131,31 @@ def test_plan_info_layout_and_blob_validation_without_gpu():
     assert lib.tfimm_hip_plan_query(junk, len(junk), ctypes.byref(info)) == -1
     assert b"plan" in lib.tfimm_hip_last_error()
     assert lib.tfimm_hip_plan_query(None, 0, ctypes.byref(info)) == -1
+
+
+def test_dp_header_symbols_exported_and_shard_bounds_without_gpu():
+    """include/tfimm_hip_dp.h (libtfimm_hip_dp.so: the data-parallel exchange step behind a C ABI): every declared symbol is
+    exported, the version matches, the shard rule is the Python one (tfimm/engine/dp.py), bad arguments come back as error
+    codes before anything touches RCCL or a device."""
+    from tfimm.engine import dp
+    hdr = open(os.path.join(ROOT, "include", "tfimm_hip_dp.h")).read()
+    names = sorted(set(re.findall(r"TFIMM_API\s+(?:const\s+)?[\w\*]+\s*\*?\s*(tfimm_hip_dp_\w+)\s*\(", hdr)))
+    assert names == sorted("tfimm_hip_dp_" + n for n in ("abi_version", "last_error", "shard_bounds", "unique_id", "create", "world",
+                                                         "all_gather_logits", "forward", "destroy")), names
+    lib = ffi.dp_lib()
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+    assert lib.tfimm_hip_dp_abi_version() == int(re.search(r"#define TFIMM_HIP_DP_ABI_VERSION (\d+)", hdr).group(1))
+    lo, hi = ctypes.c_int64(), ctypes.c_int64()
+    for batch, world in ((2048, 8), (10, 3), (7, 8), (1, 1), (0, 2)):
+        for rank in range(world):
+            assert lib.tfimm_hip_dp_shard_bounds(batch, world, rank, ctypes.byref(lo), ctypes.byref(hi)) == 0
+            assert (lo.value, hi.value) == dp.shard_bounds(batch, world, rank)
+    assert lib.tfimm_hip_dp_shard_bounds(8, 2, 2, ctypes.byref(lo), ctypes.byref(hi)) == -1
+    assert b"rank=2" in lib.tfimm_hip_dp_last_error()
+    h = ctypes.c_void_p()
+    assert lib.tfimm_hip_dp_create(ctypes.byref(h), None, 0, 1, 0, 0) == -1               # no id
+    assert lib.tfimm_hip_dp_all_gather_logits(None, None, None, 1, 1, None) == -1
+    assert lib.tfimm_hip_dp_forward(None, None, None, 0, None, 0, None, None) == -1
+    assert lib.tfimm_hip_dp_unique_id(None, 0) == -1
+    assert lib.tfimm_hip_dp_destroy(None) == 0

@@ -131,3 +131,42 @@ def test_pipelined_gather_delivers_every_step_in_order():
     for rank, ok, slots in res:
         assert ok, f"rank {rank}: gathered rows differ from what the ranks submitted"
         assert slots == [i % 2 for i in range(steps)]
+
+
+def _ragged_worker(rank, world, port, batch, cols, q):
+    sys.path.insert(0, os.path.join(ROOT, "tensorflow-image-models_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tfimm.engine import dp
+        lo, hi = dp.shard_bounds(batch, world, rank)
+        rows = max(dp.shard_bounds(batch, world, r)[1] - dp.shard_bounds(batch, world, r)[0] for r in range(world))
+        pg = dp.PipelinedGather(rows, cols, torch.float32, "cpu", dist, batch=batch)
+        ok = True
+        for step in range(3):
+            full = torch.arange(batch * cols, dtype=torch.float32).view(batch, cols) + 1000.0 * step
+            pg.submit(full[lo:hi])
+            got = pg.last()
+            ok &= got.shape == full.shape and bool(torch.equal(got, full))
+        pg.drain()
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_gather_with_ragged_shards():
+    """7 images over 2 ranks (shards of 4 and 3 rows): the short shard is padded in the send slot, every
+    rank gets the 7 valid rows back in batch order, slot reuse does not leak old padding."""
+    world, batch = 2, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, world, port, batch, 5, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res

@@ -93,17 +93,23 @@ def test_bench_two_ranks_on_one_gpu_through_its_launcher():
     assert line["config"]["launch"].startswith("hipGraph")
 
 
-def test_bench_one_rank_through_rccl():
+@pytest.mark.parametrize("exchange", ["torch", "capi"])
+def test_bench_one_rank_through_rccl(exchange):
     """The RCCL path on the hardware at hand (world = 1): communicator creation under HSA_ENABLE_IPC_MODE_LEGACY=0,
     all_gather_into_tensor of the device logits on the launch stream between hipGraph replays, the rank launcher of the
     driver's contract.  The gathered logits must be the local ones bit for bit."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--backend", "nccl", "--steps", "3",
                         "--warmup", "1", "--workload", "vit_tiny_patch16_224", "--batch", "8", "--no-cpu-baseline",
-                        "--extra", ""], capture_output=True, text=True, timeout=900, env=dict(os.environ))
+                        "--extra", ""], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, TFIMM_DP_EXCHANGE=exchange, TFIMM_BENCH_DETAIL=os.path.join(ROOT, f"bench_detail_{exchange}.json")))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
+    with open(os.path.join(ROOT, f"bench_detail_{exchange}.json")) as f:
+        mode = json.load(f)["config"]["exchange_mode"]
+    # "capi": the all-gather is issued by tfimm_hip_dp_all_gather_logits (include/tfimm_hip_dp.h), not by torch.distributed
+    assert ("through the C ABI" in mode) == (exchange == "capi"), mode
     assert line["n_gpus"] == 1 and line["config"]["ranks"] == 1 and line["config"]["launcher"] == "bench.py spawn"
     assert line["config"]["exchange"].startswith("RCCL")
     assert line["config"]["gathered_logits_bit_equal_to_local"] is True
