@@ -1,4 +1,7 @@
 """pytest -m gpu: whole-model parity, HIP engine vs fp32 CPU oracle (helpers in model_checks.py)."""
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -45,6 +48,28 @@ def test_large_configurations(name, batch):
     r = mc.compare_model(name, batch=batch)
     assert r["logits"] <= mc.TOL_LOGITS, r
     assert r["top1_agree_outside_error_band"] == 1.0, r
+
+
+# The two configurations of the 196 that the general bar does not fit (round-5 sweep: 0.25 / 0.32 rel-to-max): EfficientNetV2-XL
+# (efficientnet.py:1512), 100 blocks deep, amplifies ANY bf16 rounding under random-init weights -- the fp32 oracle itself moves
+# by 0.31 / 0.49 when only its kernels and input are rounded to bf16.  They are held to that stated, per-config bar
+# (tests/golden/bf16_bars.json "deep_configs", tools/make_bf16_sensitivity.py: a property of model + weights, computed without
+# the engine), and the float32 path of the same layer program to the reference's own 1e-3 -- which is the statement about
+# the arithmetic.
+_DEEP = {k: v for k, v in json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_bars.json")))
+         ["deep_configs"].items() if not k.startswith("_")}
+
+
+@pytest.mark.parametrize("name", sorted(_DEEP))
+def test_deep_configurations_against_their_stated_bars(name):
+    from tfimm.engine import precision
+    bar = _DEEP[name]
+    r = mc.compare_model(name, batch=bar["batch"])
+    assert r["logits"] <= bar["logits_bar"], (r, bar)
+    assert r["top1_agree_outside_error_band"] == 1.0, r
+    with precision.use("fp32"):
+        r32 = mc.compare_model(name, batch=bar["batch"])
+    assert r32["logits"] <= 1e-3 and r32["top1_agree"] == 1.0, r32
 
 
 def test_plumbing_vit_tiny_b1():
