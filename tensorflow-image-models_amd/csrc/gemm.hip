@@ -139,6 +139,20 @@ int pick_stream_tile(const tfimm_gemm_desc& d, const int* occ) {
   return best;
 }
 
+// bytes of weight panels a column-panel group may hold: 5/8 of the L2 of one XCD (hipDeviceProp_t::l2CacheSize; 4 MiB -> 2.5 MB)
+int64_t l2_budget() {
+  static int64_t v = 0;
+  if (v == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    int64_t l2 = 4 << 20;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.l2CacheSize > 0) l2 = prop.l2CacheSize;
+    if (l2 > (16 << 20)) l2 = 4 << 20;          // a runtime that reports the sum over the XCDs (or the MALL): the rule is per XCD
+    v = l2 / 8 * 5;
+  }
+  return v;
+}
+
 bool env_flag(const char* name) {
   const char* e = getenv(name);
   return e && e[0] == '1';
@@ -353,12 +367,15 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
         static const int ng_env = getenv("TFIMM_GEMM_NGROUP") ? atoi(getenv("TFIMM_GEMM_NGROUP")) : -1;
         int ng = 0;
         if (ng_env > 0) ng = ng_env;
-        else if (ng_env < 0 && w_bytes > (int64_t)(3 << 20) && ga.g.tiles_m >= 64) {
-          // as many weight panels as stay in a 4-MiB L2 next to the streaming rows: 2.5 MB of them (ViT-B, K = 768, 256-column
-          // panels of 393 KB: groups of 6 -- measured -0.9 .. -1.1 % of a ViT-B step on three boxes; 5, 7, 8 and the half split
-          // of 9 panels gain 0.2 .. 0.6 %, groups of 2 LOSE 2 %: A is re-read once per group)
+        else if (ng_env < 0 && kmode == K_DENSE && !scale && w_bytes > (int64_t)(3 << 20) && ga.g.tiles_m >= 64) {
+          // as many weight panels as stay in one XCD's L2 next to the streaming rows: 5/8 of it (4 MiB on MI355X -> 2.5 MB;
+          // ViT-B, K = 768, 256-column panels of 393 KB: groups of 6 -- measured -0.9 .. -1.1 % of a ViT-B step on three boxes;
+          // 5, 7, 8 and the half split of 9 panels gain 0.2 .. 0.6 %, groups of 2 LOSE 2 %: A is re-read once per group).
+          // Dense rows only (plain and LayerNorm-folded -- both ViT-B flavours were in that measurement): an implicit-GEMM
+          // convolution re-gathers A per group and the SE-gate flavour re-scales it; their table entries were timed in
+          // M-panel-major order.
           const int64_t panel = (int64_t)t->bn * d.ldw * 2;
-          ng = (int)((int64_t)2621440 / (panel > 0 ? panel : 1));
+          ng = (int)(l2_budget() / (panel > 0 ? panel : 1));
           if (ng < 3) ng = 0;
         }
         ga.ngroup = (ng > 0 && ng < ga.g.tiles_n) ? ng : 0;

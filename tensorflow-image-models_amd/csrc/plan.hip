@@ -229,10 +229,12 @@ int parse(const void* blob, size_t bytes, Plan& pl) {
   for (const auto& o : pl.outputs) {
     if (o.slab >= pl.slab_off.size()) TFIMM_FAIL(TFIMM_EINVAL, "plan: output '%s' outside its slab", o.name.c_str());
     const uint64_t cap = pl.slab_bytes[o.slab], esz = o.dtype == 1 ? 4 : 2;
-    bool ok = o.offset < cap && o.cols > 0 && o.rows_per_image > 0 && o.cols <= kMaxBuf && o.rows_per_image <= kMaxBuf;
+    // every product is checked by DIVISION before it is formed: rows_per_image < 2^40 times an unbounded 32-bit batch, or
+    // rows times cols, wrap in 64 bits (rows = cols = 2^32 gives 0 and passed the multiplied form of this check)
+    bool ok = o.offset < cap && o.cols > 0 && o.rows_per_image > 0 && pl.batch > 0 && o.cols <= kMaxBuf && o.rows_per_image <= kMaxBuf / pl.batch;
     if (ok) {
-      const uint64_t rows = o.rows_per_image * (uint64_t)pl.batch;            // < 2^72 cannot happen: both factors bounded above
-      ok = rows <= kMaxBuf && rows * o.cols <= kMaxBuf && rows * o.cols * esz <= cap - o.offset;
+      const uint64_t rows = o.rows_per_image * (uint64_t)pl.batch;            // <= kMaxBuf by the division above
+      ok = o.cols <= kMaxBuf / rows && rows * o.cols <= (cap - o.offset) / esz;
     }
     if (!ok) TFIMM_FAIL(TFIMM_EINVAL, "plan: output '%s' outside its slab", o.name.c_str());
   }

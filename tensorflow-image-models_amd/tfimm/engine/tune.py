@@ -56,9 +56,14 @@ def strip_shape(d) -> bool:
     before it honours the hint: 3 x 3 / stride 1 / pad 1 convolution of 128 -> 128 channels, rows of at most 31 pixels, same
     output size, no residual, bf16 output.  For any other shape the library answers hint 31 with its cost model, i.e. the
     tuner would time hint 0 twice and could record 31 from noise (tests/test_tune_table.py rejects such entries)."""
+    pitch = getattr(d, "pix_pitch", 0) or d.Cin
     return (int(d.mode) != 0 and d.KH == 3 and d.KW == 3 and d.stride == 1 and d.Cin == 128 and d.N == 128 and 0 < d.W <= 31
             and getattr(d, "pad_t", 1) == 1 and getattr(d, "pad_l", 1) == 1 and getattr(d, "OH", d.H) == d.H
-            and getattr(d, "OW", d.W) == d.W and not d.residual and not d.out_f32 and not getattr(d, "a_scale", None))
+            and getattr(d, "OW", d.W) == d.W and not d.residual and not d.out_f32 and not getattr(d, "a_scale", None)
+            # ... and the rest of what tfimm_hip_gemm asks before it honours hint 31 (csrc/gemm.hip): the default stride in w, no row
+            # remap, no folded LayerNorm, K-padded weights, a pixel pitch of exactly 128 channels, 16-byte aligned output rows
+            and getattr(d, "stride_w", 0) in (0, d.stride) and getattr(d, "remap_in", 0) == 0 and not getattr(d, "ln_stats", None)
+            and getattr(d, "ldw", d.K) >= d.K and pitch == 128 and d.ldc % 8 == 0)
 
 
 def candidates_for(d):

@@ -48,12 +48,15 @@ def test_committed_table_is_well_formed():
 
 def test_strip_hint_is_a_candidate_only_for_the_strip_shape():
     """Hint 31 falls back to the cost model inside the library for every other shape: offering it there would time hint 0 twice."""
-    strip = _desc(mode=1, M=6 * 784, N=128, K=1152, lda=128, ldc=128, B=6, H=28, W=28, Cin=128, KH=3, KW=3, stride=1,
+    strip = _desc(mode=1, M=6 * 784, N=128, K=1152, lda=128, ldc=128, ldw=1152, B=6, H=28, W=28, Cin=128, KH=3, KW=3, stride=1,
                   pad_t=1, pad_l=1, OH=28, OW=28)
     assert tune.strip_shape(strip) and 31 in tune.candidates_for(strip)
     for change in (dict(W=32, OW=32), dict(Cin=64), dict(N=256), dict(stride=2), dict(KH=1, KW=1), dict(residual=0x1000),
-                   dict(out_f32=1), dict(pad_t=0), dict(OH=27)):
-        d = _desc(mode=1, M=6 * 784, N=128, K=1152, lda=128, ldc=128, B=6, H=28, W=28, Cin=128, KH=3, KW=3, stride=1,
+                   dict(out_f32=1), dict(pad_t=0), dict(OH=27),
+                   # (ADVICE r05) the rest of what tfimm_hip_gemm checks before it honours the hint
+                   dict(remap_in=196, remap_out=197), dict(ln_stats=0x1000, ln_c1=0x2000), dict(ldw=1024), dict(pix_pitch=256),
+                   dict(ldc=132), dict(stride_w=2)):
+        d = _desc(mode=1, M=6 * 784, N=128, K=1152, lda=128, ldc=128, ldw=1152, B=6, H=28, W=28, Cin=128, KH=3, KW=3, stride=1,
                   pad_t=1, pad_l=1, OH=28, OW=28)
         for k, v in change.items():
             setattr(d, k, v)
