@@ -132,7 +132,7 @@ def measured_traffic(workload, batch):
     (FETCH_SIZE / WRITE_SIZE need their own profiler passes and cannot be collected from inside this process):
     tools/gpu_traffic.sh.  Returns (bytes per launch, source) -- a constant from that profile, not a counter of this run;
     None when no profile of this workload / batch exists."""
-    for rel in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json"):            # the newest committed profile
+    for rel in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json"):            # the newest committed profile
         path = os.path.join(ROOT, "profiles", rel)
         if batch == WORKLOADS.get(workload, {}).get("batch") and os.path.exists(path):
             with open(path) as f:

@@ -29,8 +29,8 @@ def family(k):
     return "other"
 res = {"_doc": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over eager bench.py steps; bytes per step and per "
                "launch of the workload's roofline family; FETCH_SIZE x 2 (gfx950 wide-read correction), counters in KiB",
-       "steps_profiled": steps + warm, "workloads": {}}
-n = steps + warm
+       "steps_profiled": warm + 2 * steps, "workloads": {}}
+n = warm + 2 * steps      # bench.py --no-graph launches W warm-up + K timed steps + K more for the per-step medians (a pass of its own since round 5)
 for w in sys.argv[4:]:
     out = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
