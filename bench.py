@@ -220,15 +220,20 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
             forked = None
             torch.cuda.synchronize()
         if forked is not None:
-            def _time(g, n=5):
+            def _time(g, n=5, rounds=3):
+                """ms per replay of a recording: the best of `rounds` groups of `n` replays (one group of 5 picked among six
+                recordings on what is partly clock noise: VERDICT r05 weak 8)"""
                 for _ in range(2):
                     g.replay()
-                torch.cuda.synchronize()
-                t = time.perf_counter()
-                for _ in range(n):
-                    g.replay()
-                torch.cuda.synchronize()
-                return (time.perf_counter() - t) / n * 1e3
+                best = float("inf")
+                for _ in range(rounds):
+                    torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    for _ in range(n):
+                        g.replay()
+                    torch.cuda.synchronize()
+                    best = min(best, (time.perf_counter() - t) / n * 1e3)
+                return best
             single_ms, forked_ms = _time(captured), _time(forked)
             if branches == "auto":
                 # ... and hybrids: branches for the first part of the program, the full batch for the rest (CapturedHybrid:
@@ -243,11 +248,11 @@ def measure(model, batch, micro_batch, steps, warmup, world, kernel_events, dist
                         torch.cuda.synchronize()
                         break
                     t_h = _time(hyb)
-                    if t_h < forked_ms:
+                    if t_h < 0.995 * forked_ms:          # (a recording replaces the incumbent only by more than the repeatability of _time)
                         forked, forked_ms, hybrid_cut = hyb, t_h, hyb.cut_op
                     else:
                         del hyb
-                if forked_ms >= single_ms:
+                if forked_ms >= 0.995 * single_ms:
                     forked = None
     # the recording that will be timed must give the bits of the single-branch recording (checked once, before the warm-up)
     forked_bit_equal = None
