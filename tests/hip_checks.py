@@ -181,7 +181,11 @@ for _t in (1, 21, 22, 23, 24, 25, 26, 27, 29):
         lambda t=_t: _se_scale_case(11, 144, 200, 72, 110 + t, tile=t, residual=True, bias=True))
 CASES["gemm_se_scale_t24_r2304_k960"] = lambda: _se_scale_case(5, 2304, 960, 160, 130, tile=24, residual=True)   # several gate pieces per slot
 CASES["gemm_se_scale_t23_r9025_k144_multiround"] = lambda: _se_scale_case(9, 9025, 144, 32, 131, tile=23, bias=True)
-CASES["gemm_se_scale_t21_r36_k2688"] = lambda: _se_scale_case(40, 36, 2688, 448, 132, tile=21)   # 9 images per tile: gate buffers fit only for a narrow tile -> falls back
+# (round 6: the gate arrives per k-tile, 1 KiB per four image slots -- csrc/gemm_stream_kernel.h issue_gate)
+CASES["gemm_se_scale_t21_r36_k2688"] = lambda: _se_scale_case(40, 36, 2688, 448, 132, tile=21)   # 9 image slots per tile: three gate pieces per k-tile
+CASES["gemm_se_scale_t23_r36_k2688"] = lambda: _se_scale_case(40, 36, 2688, 448, 133, tile=23, residual=True)   # 128-row tile, 5 slots: two pieces on four waves
+CASES["gemm_se_scale_t21_r4_falls_back"] = lambda: _se_scale_case(70, 4, 200, 72, 134, tile=21, bias=True)     # 65 slots = 17 pieces > 8 waves: register-staged kernel
+CASES["gemm_se_scale_t25_r49_k1152"] = lambda: _se_scale_case(37, 49, 1152, 192, 135, tile=25, residual=True)  # 7 x 7 images (EfficientNet-B0's last stage), odd image count
 
 
 @case("gemm_row_select_lda")
