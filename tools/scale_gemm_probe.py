@@ -2,7 +2,8 @@
 launch (best of `rounds` interleaved passes of `iters` launches), so that the table entries of those shapes can be chosen from
 numbers instead of from one noisy tuner pass.
 
-    python tools/scale_gemm_probe.py [iters] [rounds]        -> gpurun_out/scale_gemm_probe.txt
+    python tools/scale_gemm_probe.py [iters] [rounds] [batch]      -> gpurun_out/scale_gemm_probe[_b<batch>].txt
+(batch 128 = the shapes of the two half-batch branches bench.py replays)
 """
 import os
 import sys
@@ -15,17 +16,18 @@ import torch  # noqa: E402
 import hip_ops as H  # noqa: E402
 from tfimm.engine import tune  # noqa: E402
 
-# (M, K, N, rows per image, residual)
-SHAPES = [(36864, 1632, 272, 144, True), (36864, 1632, 448, 144, False), (36864, 2688, 448, 144, True),
-          (36864, 960, 272, 144, False), (147456, 960, 160, 576, True), (147456, 672, 160, 576, False),
-          (147456, 672, 112, 576, True), (147456, 336, 112, 576, False), (589824, 336, 56, 2304, True),
-          (589824, 192, 56, 2304, False), (2310400, 192, 32, 9025, True), (2310400, 144, 32, 9025, False)]
+# (K, N, rows per image, residual); M = batch x rows per image
+LAYERS = [(1632, 272, 144, True), (1632, 448, 144, False), (2688, 448, 144, True), (960, 272, 144, False),
+          (960, 160, 576, True), (672, 160, 576, False), (672, 112, 576, True), (336, 112, 576, False),
+          (336, 56, 2304, True), (192, 56, 2304, False), (192, 32, 9025, True), (144, 32, 9025, False)]
 HINTS = [0, 21, 22, 23, 24, 25, 26, 27, 29, 30, 1, 2, 3, 4, 5, 6]
 
 
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+    SHAPES = [(batch * R, K, N, R, res) for K, N, R, res in LAYERS]
     lines = ["shape (M K N rows/img res)".ljust(34) + "table " + " ".join(f"{h:>6d}" for h in HINTS)]
     for M, K, N, R, has_res in SHAPES:
         a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
@@ -71,7 +73,7 @@ def main():
         del a, w, g, out, res
         torch.cuda.empty_cache()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "scale_gemm_probe.txt"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "scale_gemm_probe.txt" if batch == 256 else f"scale_gemm_probe_b{batch}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
 
 
