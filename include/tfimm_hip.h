@@ -31,7 +31,8 @@ extern "C" {
 #endif
 
 /* 3: tfimm_tha_desc grew (proj_dev), tfimm_hip_mlp_fused / tfimm_hip_plan_* / tfimm_hip_ref_* added (round 3) */
-#define TFIMM_HIP_ABI_VERSION 3
+/* 4: tfimm_gemm_desc grew (a2 ...: a second A operand, the shortcut convolution folded into a block's last GEMM; round 6) */
+#define TFIMM_HIP_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define TFIMM_API __attribute__((visibility("default")))
@@ -128,6 +129,17 @@ typedef struct tfimm_gemm_desc {
                              ROUNDED weights and bias = beta . W + b.  The normalised tensor is never written. */
   const void* ln_c1;      /* bf16 [N][2][8]: c1[n] as the three-term bf16 split (ca, cb, cc), laid out as the MFMA fragment
                              pair {ca,cb,cc,ca,cb,cc,ca,cb} {cc,0,0,0,0,0,0,0} (tfimm/engine/pack.py: pack_ln_c1) */
+  /* ---- ABI v4: a SECOND A operand whose product accumulates into the same output tile (dense mode, no residual):
+   *      out = act( a . wt[:, 0:K]^T + a2' . wt[:, Kp:Kp+K2]^T + bias ),   Kp = K rounded up to 64.
+   * It is the shortcut convolution of a residual block folded into the block's last 1x1 convolution (resnet.py:282-290
+   * `x = self.conv3(x) ... shortcut = self.downsample(shortcut) ... x += shortcut`, downsample_conv resnet.py:315-330: a 1x1
+   * convolution of stride s + BatchNorm): instead of writing the shortcut tensor and reading it back as `residual`, its K2
+   * input channels are more k-tiles of the same GEMM (the two folded BatchNorm shifts are added on the host).  a2' is the
+   * strided row view of a2: output row m = (b, oy, ox) of an [a2_OH][a2_OW] image reads pixel (b, oy * a2_stride,
+   * ox * a2_stride) of the [a2_H][a2_W][lda2] tensor a2 (a2_stride = 1: row m itself).  NULL = no second operand. */
+  const void* a2;         /* bf16 [B * a2_H * a2_W][lda2] */
+  int32_t K2, lda2;       /* channels of the second operand (multiple of 8) and its pixel pitch in elements */
+  int32_t a2_stride, a2_H, a2_W, a2_OH, a2_OW;
 } tfimm_gemm_desc;
 
 TFIMM_API int tfimm_hip_gemm(const tfimm_gemm_desc* d, void* stream);

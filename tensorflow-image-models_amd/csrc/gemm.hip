@@ -199,10 +199,26 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
   if (d.ln_stats && (d.mode != TFIMM_A_DENSE || d.residual || d.a_scale || d.out_f32 || (((uintptr_t)d.ln_stats | (uintptr_t)d.ln_c1) & 15)))
     TFIMM_FAIL(TFIMM_EINVAL, "gemm: LayerNorm folding needs a dense bf16 layer without residual / gate and 16-byte aligned tables");
 
+  if (d.a2) {
+    // second A operand (ABI v4): the shortcut convolution of a residual block as further k-tiles of this GEMM
+    if (d.mode != TFIMM_A_DENSE || d.residual || d.a_scale || d.ln_stats || d.out_f32 || d.remap_in || d.res_mod)
+      TFIMM_FAIL(TFIMM_EINVAL, "gemm: a second A operand needs a dense bf16 layer without residual / gate / LayerNorm / row remap");
+    if (d.K2 <= 0 || (d.K2 & 7) || d.lda2 < d.K2 || (d.lda2 & 7) || ((uintptr_t)d.a2 & 15))
+      TFIMM_FAIL(TFIMM_EINVAL, "gemm: a2 needs K2=%d %% 8 == 0, lda2=%d >= K2 and %% 8 == 0, a 16-byte aligned pointer", d.K2, d.lda2);
+    if (d.a2_stride < 1) TFIMM_FAIL(TFIMM_EINVAL, "gemm: a2_stride=%d", d.a2_stride);
+    if (d.a2_stride > 1) {
+      if (d.a2_H <= 0 || d.a2_W <= 0 || d.a2_OH <= 0 || d.a2_OW <= 0 || d.M % ((int64_t)d.a2_OH * d.a2_OW) ||
+          (d.a2_OH - 1) * d.a2_stride >= d.a2_H || (d.a2_OW - 1) * d.a2_stride >= d.a2_W)
+        TFIMM_FAIL(TFIMM_EINVAL, "gemm: a2 geometry %dx%d -> %dx%d at stride %d (M=%d)", d.a2_H, d.a2_W, d.a2_OH, d.a2_OW, d.a2_stride, d.M);
+    }
+    const int64_t kp = cdiv64(d.K, 64) * 64;
+    if (d.ldw < kp + d.K2) TFIMM_FAIL(TFIMM_EINVAL, "gemm: ldw=%d < %lld + K2=%d (the second operand's weights start at column ceil64(K))", d.ldw, (long long)kp, d.K2);
+  }
+
   // The LDS-DMA kernels address every tensor through a buffer descriptor with a 32-bit byte offset.  A plain
   // dense GEMM whose activation, output or residual exceeds 2 GiB (EfficientNet-B4's first expand layer at batch 256:
   // 9.2 M rows x 144 channels) is therefore run as row chunks that each fit, instead of leaving those families.
-  if (d.mode == TFIMM_A_DENSE && !d.a_scale && d.remap_in == 0 && d.res_mod == 0) {
+  if (d.mode == TFIMM_A_DENSE && !d.a_scale && !d.a2 && d.remap_in == 0 && d.res_mod == 0) {
     const int64_t row_bytes = std::max<int64_t>(std::max<int64_t>((int64_t)d.lda * 2, (int64_t)d.ldc * (d.out_f32 ? 4 : 2)),
                                                  d.residual ? (int64_t)d.ldr * 2 : 0);
     const int64_t limit = 0x7fffff00LL;
@@ -298,9 +314,13 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
     const int64_t res_rows = d.res_mod > 0 ? (d.res_mod < d.M ? d.res_mod : d.M) : d.M;
     const int64_t res_bytes = d.residual ? ((res_rows - 1) * d.ldr + d.N) * 2 : 0;
     const bool scale = kmode == K_DENSE_SCALE;
-    const bool ok = (kmode == K_DENSE || kmode == K_CONV || scale) && !hinted_other && !stream_disabled() && !dma_disabled() &&
+    const bool dual = d.a2 != nullptr;
+    const int64_t a2_rows = !dual ? 0 : d.a2_stride > 1 ? (int64_t)(d.M / ((int64_t)d.a2_OH * d.a2_OW)) * d.a2_H * d.a2_W : d.M;
+    const int64_t a2_bytes = dual ? ((a2_rows - 1) * d.lda2 + d.K2) * 2 : 0;
+    const bool ok = (kmode == K_DENSE || kmode == K_CONV || scale) && (!hinted_other || dual) && !stream_disabled() && !dma_disabled() &&
                     d.ldw >= (int)(cdiv64(d.K, 64) * 64) && a_bytes <= 0x7fffff00LL && w_bytes <= 0x7fffff00LL &&
-                    out_bytes <= 0x7fffff00LL && res_bytes <= 0x7fffff00LL;
+                    out_bytes <= 0x7fffff00LL && res_bytes <= 0x7fffff00LL && a2_bytes <= 0x7fffff00LL &&
+                    (!dual || (kmode == K_DENSE && d.ldw >= (int)(cdiv64(d.K, 64) * 64 + cdiv64(d.K2, 64) * 64)));
     if (ok) {
       const int fi = kmode == K_CONV ? 1 : 0;
       // vector epilogue: whole 16-byte groups per lane on aligned rows
@@ -336,11 +356,18 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       for (int i = 0; i < TFIMM_GEMM_STREAM_NUM_TILES; ++i) occ_f[i] = occ[i][fi];
       int ti = pick_stream_tile(d, occ_f);
       // the two-workgroups-per-CU tile: vector epilogues only, at least two 32-wide k-tiles; otherwise the 256x128 stream tile
-      if (ti == 9 && (ei == 0 || d.K <= 32 || scale)) ti = 1;
+      if (ti == 9 && (ei == 0 || d.K <= 32 || scale || dual)) ti = 1;
       const StreamTileCfg* t = stream_tile_table(ti);
       if (scale && !t->fn_scale[ei]) {   // the deep-ring tile has no SE-gate flavour
         ti = 0;
         t = stream_tile_table(ti);
+      }
+      if (dual) {
+        if (ei != 2) TFIMM_FAIL(TFIMM_EUNSUP, "gemm: a second A operand needs N %% 8 == 0 and 16-byte aligned bf16 output rows");
+        if (!t->fn_dual) {
+          ti = 0;
+          t = stream_tile_table(ti);
+        }
       }
       const bool ln_in = d.ln_stats != nullptr;
       if (ln_in) {
@@ -407,6 +434,8 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       const int64_t need = (ntiles + 7) / 8 * 8;
       if (grid > need) grid = need;
       ga.s_bytes = 0; ga.s_slots = ga.s_gp = 0;
+      ga.a2 = (const bf16_t*)d.a2; ga.a2_bytes = (unsigned)a2_bytes;
+      ga.K2 = d.K2; ga.lda2 = d.lda2; ga.a2_stride = d.a2_stride; ga.a2_H = d.a2_H; ga.a2_W = d.a2_W; ga.a2_OH = d.a2_OH; ga.a2_OW = d.a2_OW;
       ga.ln_stats = d.ln_stats; ga.ln_c1 = d.ln_c1;
       ga.ln_stats_bytes = ln_in ? (unsigned)((int64_t)d.M * 8) : 0u;
       ga.ln_c1_bytes = ln_in ? (unsigned)((int64_t)d.N * 32) : 0u;
@@ -424,6 +453,15 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
         grid = ((int64_t)num_cu() * ln_occ[ti] + 7) / 8 * 8;
         if (grid > need) grid = need;
         TFIMM_LAUNCH(t->fn_ln, dim3((unsigned)grid), dim3(t->threads), lds, (hipStream_t)stream, ga);
+        return 0;
+      }
+      if (dual) {
+        static tfimm_once_t dual_attr[TFIMM_GEMM_STREAM_NUM_TILES];
+        if (dual_attr[ti].need()) {
+          TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)t->fn_dual, hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_bytes));
+          dual_attr[ti].mark();
+        }
+        TFIMM_LAUNCH(t->fn_dual, dim3((unsigned)grid), dim3(t->threads), (size_t)t->lds_bytes, (hipStream_t)stream, ga);
         return 0;
       }
       if (!scale) {
@@ -457,6 +495,7 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
   }
 
   if (d.ln_stats) TFIMM_FAIL(TFIMM_EUNSUP, "gemm: LayerNorm folding needs the persistent LDS-DMA family (K-padded weights, 16-byte aligned rows)");
+  if (d.a2) TFIMM_FAIL(TFIMM_EUNSUP, "gemm: a second A operand needs the persistent LDS-DMA family (K %% 8 == 0, K-padded weights, 16-byte aligned rows)");
   if (d.mode != TFIMM_A_DENSE && g.stride_w != g.stride)
     TFIMM_FAIL(TFIMM_EUNSUP, "gemm: stride_w != stride needs the persistent LDS-DMA family (Cin %% 8 == 0, 16-byte aligned input)");
 

@@ -47,6 +47,12 @@ struct GemmStreamArgs {
   unsigned s_bytes;   // extent of the gate table
   int s_slots;        // image slots per tile: ceil(BM / rows_per_image) + 1
   int s_gp;           // 1-KiB DMA pieces per k-tile: ceil(s_slots / 4) (four slots of 256 bytes each), one per wave 0 .. s_gp-1
+  // DUAL flavour (tfimm_gemm_desc::a2): a second dense A operand whose K2 channels are further k-tiles of the same tile -- the
+  // shortcut convolution of a residual block inside the block's last 1x1 convolution.  Row m of the output reads row
+  // a2_row(m) of a2: m itself at stride 1, pixel (b, oy s, ox s) of an [a2_H][a2_W] image at stride s.
+  const bf16_t* a2;
+  unsigned a2_bytes;
+  int K2, lda2, a2_stride, a2_H, a2_W, a2_OH, a2_OW;
   // LNIN flavour (LayerNorm folded into this GEMM): per-row (mean, rstd) and the split column sums of the gamma-scaled weights
   const float* ln_stats;      // fp32 [M][2]
   const void* ln_c1;          // bf16 [N][2][8] correction fragments (pack.pack_ln_c1)
@@ -81,7 +87,8 @@ struct StreamGeom {
 // -mean_m * c1[n] is a rank-1 update: ONE extra MFMA k-step per accumulator block whose operands are the bf16 three-way splits
 // of -mean_m (built in registers) and of c1[n] (host-packed), nine exact products that carry ~24 bits; rstd_m rides on the
 // bias FMA.  Statistics and correction fragments of a tile arrive by LDS-DMA at tile start (no registers across the K loop).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int KMODE, bool VEC, bool SCALE = false, bool NORES = false, bool LNIN = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int KMODE, bool VEC, bool SCALE = false, bool NORES = false, bool LNIN = false,
+          bool DUAL = false>
 __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(const GemmStreamArgs pa) {
   using G = StreamGeom<BM, BN, WAVES_M, WAVES_N>;
   const GemmArgs& p = pa.g;
@@ -95,6 +102,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   static_assert(WTN == 32 || WTN == 64, "epilogue swizzle is written for 32/64-wide wave tiles");
   static_assert(!SCALE || KMODE == K_DENSE, "the SE-gate prologue exists for dense rows");
   static_assert(!LNIN || (VEC && NORES && !SCALE && KMODE == K_DENSE), "LayerNorm folding: dense rows, residual-free vector epilogue");
+  static_assert(!DUAL || (VEC && NORES && !SCALE && !LNIN && KMODE == K_DENSE), "second A operand: dense rows, residual-free vector epilogue");
   constexpr int A_BYTES = G::A_BYTES, STAGE = G::STAGE;
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
@@ -138,6 +146,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   const __amdgpu_buffer_rsrc_t rsrc_r = make_rsrc(p.residual, pa.res_bytes);
   const __amdgpu_buffer_rsrc_t rsrc_s = LNIN ? make_rsrc(pa.ln_stats, pa.ln_stats_bytes) : make_rsrc(p.a_scale, SCALE ? pa.s_bytes : 0u);
   const __amdgpu_buffer_rsrc_t rsrc_c = make_rsrc(pa.ln_c1, LNIN ? pa.ln_c1_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rsrc_a2 = make_rsrc(pa.a2, DUAL ? pa.a2_bytes : 0u);
   // LNIN: this wave's private LDS block behind the operand ring: 1 KiB of (mean, rstd) pairs for 128 rows, then TN x 1 KiB
   // of correction fragments (one 16-byte fragment per lane and 32-column block)
   char* const lnw = smem + G::LDS_BYTES + wave * (1 + TN) * 1024;
@@ -145,12 +154,14 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   char* const sS = smem + G::LDS_BYTES;
   const int s_gbytes = SCALE ? pa.s_gp * 1024 : 0;
 
-  const int nk = (p.K + BK - 1) / BK;
+  const int nk1 = (p.K + BK - 1) / BK;                          // k-tiles of the (first) A operand
+  const int nk = nk1 + (DUAL ? (pa.K2 + BK - 1) / BK : 0);      // DUAL: the second operand's follow (weights: column nk1 * 64 on)
   const int lrow = lane >> 3;   // row within an 8-row DMA piece
   const int lpc = lane & 7;     // physical 16-byte chunk this lane fills
 
   // ---- DMA source state of the tile being ISSUED (one step ahead of the tile being computed)
   unsigned a_off[A_INSTR];      // dense: byte offset of (row, chunk) at k = 0, or kOobOffset
+  unsigned a_off2[DUAL ? A_INSTR : 1];   // DUAL: the same for the second operand
   int a_iy0[A_INSTR], a_ix0[A_INSTR], a_pix[A_INSTR];
   unsigned b_off[B_INSTR];
   int s_ky = 0, s_kx = 0, s_ci0 = 0;   // K_CONV + cin64: wave-uniform tap state of the next k-tile
@@ -182,6 +193,17 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
 #endif
         a_off[j] = ok ? (unsigned)(((size_t)msrc * p.lda + a_chunk(j) * 8) * 2) : kOobOffset;
         a_iy0[j] = a_ix0[j] = a_pix[j] = 0;
+        if (DUAL) {
+          int r2 = m;
+          if (pa.a2_stride > 1) {                      // (b, oy, ox) of the output row -> pixel (b, oy s, ox s) of the input image
+            const int mm = ok ? m : 0;
+            const int ohw = pa.a2_OH * pa.a2_OW;
+            const int b = mm / ohw, rem = mm - b * ohw;
+            const int oy = rem / pa.a2_OW, ox = rem - oy * pa.a2_OW;
+            r2 = (b * pa.a2_H + oy * pa.a2_stride) * pa.a2_W + ox * pa.a2_stride;
+          }
+          a_off2[j] = ok ? (unsigned)(((size_t)r2 * pa.lda2 + a_chunk(j) * 8) * 2) : kOobOffset;
+        }
       } else {
         const int mm = ok ? m : 0;
         const int ohw = p.OH * p.OW;
@@ -229,10 +251,18 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
                                                (int)b_off[j], kbytes, 0, 0);
     } else if (KMODE == K_DENSE) {
       const int j = piece - B_INSTR;
-      const bool kok = (kt * BK + a_chunk(j) * 8) < p.K;
-      const unsigned off = kok ? a_off[j] : kOobOffset;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sa + (wave * A_INSTR + j) * 1024), 16,
-                                               (int)off, kbytes, 0, 0);
+      if (DUAL && kt >= nk1) {      // (wave-uniform) a k-tile of the second operand
+        const int kt2 = kt - nk1;
+        const bool kok = (kt2 * BK + a_chunk(j) * 8) < pa.K2;
+        const unsigned off = kok ? a_off2[j] : kOobOffset;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a2, (lds_ptr_t)(sa + (wave * A_INSTR + j) * 1024), 16,
+                                                 (int)off, kt2 * 128, 0, 0);
+      } else {
+        const bool kok = (kt * BK + a_chunk(j) * 8) < p.K;
+        const unsigned off = kok ? a_off[j] : kOobOffset;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sa + (wave * A_INSTR + j) * 1024), 16,
+                                                 (int)off, kbytes, 0, 0);
+      }
     } else {
       const int j = piece - B_INSTR;
       int ky, kx, ci;
@@ -792,6 +822,7 @@ struct StreamTileCfg {
   int bm, bn, threads, lds_bytes;
   gemm_stream_fn fn[2][3];     // [K_DENSE, K_CONV][catch-all, VEC, VEC without residual]
   gemm_stream_fn fn_scale[3];  // K_DENSE + SE gate on A, same three epilogues (null: not built for this tile)
+  gemm_stream_fn fn_dual;      // K_DENSE + a second A operand, residual-free vector epilogue (null: not built for this tile)
   gemm_stream_fn fn_ln;        // K_DENSE, VEC without residual, LayerNorm folded in (LNIN); needs ln_lds extra bytes of LDS
   int ln_lds;
 };

@@ -257,6 +257,7 @@ class ResNet(Model):
             p = f"layer{idx + 1}/{bidx}"
             shortcut = x
             ds_spec = None
+            fold_spec = None            # (x, kernel, bn, stride, emit): the shortcut convolution as a second operand of conv3
             if down:
                 if c.downsample_mode == "avg":
                     # resnet.py:295-312 (ResNet-D): AveragePooling2D(2, stride, "same") -> 1x1 conv -> norm.  At even
@@ -286,6 +287,12 @@ class ResNet(Model):
                             and os.environ.get("TFIMM_NO_CHAIN_SHORTCUT", "0") != "1"):
                         shortcut = None
                         ds_spec = (x, p + "/downsample/0/kernel", p + "/downsample/1", emit_shortcut)
+                    elif (c.block == "bottleneck" and c.down_kernel_size == 1 and not gn
+                          and b.can_fold_shortcut(x, stride, out_ch)):
+                        # any other 1x1 shortcut convolution of a bottleneck (the strided first blocks of stages 2 - 4): its input
+                        # channels become further k-tiles of conv3 (tfimm_gemm_desc::a2) -- no shortcut tensor, no launch
+                        shortcut = None
+                        fold_spec = (x, p + "/downsample/0/kernel", p + "/downsample/1", stride, emit_shortcut)
                     else:
                         shortcut = emit_shortcut()
             se = c.attn_layer == "se"
@@ -293,6 +300,8 @@ class ResNet(Model):
             use_aa = bool(c.aa_layer) and stride == 2                                  # resnet.py:127,218
             if ds_spec is not None and (gated or use_aa or c.cardinality != 1 or act != "relu"):
                 shortcut, ds_spec = ds_spec[3](), None       # the fused tail will not be used: emit the shortcut now
+            if fold_spec is not None and gated:              # the gate multiplies conv3's output only: the add stays separate
+                shortcut, fold_spec = fold_spec[4](), None
             last = dict(residual=None if gated else shortcut, act="" if gated else act, act_after=not gated)
             cstride = 1 if use_aa else stride
             if c.block == "basic_block":
@@ -329,7 +338,7 @@ class ResNet(Model):
                     k2 = b.define(k2 + ":dense", _expand_grouped_kernel(kg, c.cardinality))
                     kw2["flops_k"] = 9 * y.C // c.cardinality
                 fused = None
-                if not gn and not gated and not use_aa and c.cardinality == 1 and act == "relu":
+                if not gn and not gated and not use_aa and c.cardinality == 1 and act == "relu" and fold_spec is None:
                     # conv2 + bn2 + act2 + conv3 + bn3 + shortcut add + act3 as one launch: the `width`-channel
                     # intermediate stays in LDS (stages 1 and 2; None for shapes that kernel is not built for)
                     fused = b.conv_chain(y, k2, p + "/bn2", p + "/conv3/kernel", p + "/bn3", stride=cstride, padding=1,
@@ -345,7 +354,14 @@ class ResNet(Model):
                                                                       cite="resnet.py:273-276", **kw2)
                     if use_aa:
                         y = b.blur_pool(y, stride, cite="resnet.py:277-278")
-                    y = conv_norm(y, p + "/conv3/kernel", p + "/bn3", cite="resnet.py:280-290", **last)
+                    if fold_spec is not None and not b.can_fold_shortcut(fold_spec[0], fold_spec[3], out_ch, y.C):
+                        shortcut, fold_spec = fold_spec[4](), None          # conv3's own input is not 16-byte aligned: the plain form
+                        last = dict(residual=shortcut, act=act, act_after=True)
+                    if fold_spec is not None:
+                        y = conv_norm(y, p + "/conv3/kernel", p + "/bn3", act=act, fold_shortcut=fold_spec[:4],
+                                      cite="resnet.py:280-290 + 315-330")
+                    else:
+                        y = conv_norm(y, p + "/conv3/kernel", p + "/bn3", cite="resnet.py:280-290", **last)
             if c.attn_layer == "eca":
                 # EcaModule (layers/attention.py:105-130): fp32 channel means -> Conv1D over the channel axis -> sigmoid
                 m = b.mean_rows(y, out_f32=True, cite="layers/attention.py:122")

@@ -38,6 +38,9 @@ class GemmDesc(C.Structure):
         ("rows_per_image", C.c_int32), ("tile_hint", C.c_int32), ("stride_w", C.c_int32),
         ("pix_pitch", C.c_int32),
         ("ln_stats", C.c_void_p), ("ln_c1", C.c_void_p),
+        # ABI v4: a second A operand (the shortcut convolution of a residual block folded into its last 1x1 convolution)
+        ("a2", C.c_void_p), ("K2", C.c_int32), ("lda2", C.c_int32),
+        ("a2_stride", C.c_int32), ("a2_H", C.c_int32), ("a2_W", C.c_int32), ("a2_OH", C.c_int32), ("a2_OW", C.c_int32),
     ]
 
 
@@ -183,12 +186,16 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the ABI drifted
         fn.restype = res
         fn.argtypes = args
-    if lib.tfimm_hip_abi_version() != 3:
+    # 4 = this tree.  3 (tfimm_gemm_desc without the second A operand) is accepted ONLY for a library named by TFIMM_HIP_LIB --
+    # an older build in a kernel A/B; the lowering then does not emit what that build cannot run (ABI below)
+    v = lib.tfimm_hip_abi_version()
+    if v != 4 and not (v == 3 and os.environ.get("TFIMM_HIP_LIB")):
         raise ImportError("libtfimm_hip.so ABI version mismatch")
     return lib
 
 
 lib = _load()
+ABI = lib.tfimm_hip_abi_version()
 
 
 _dp_lib = None

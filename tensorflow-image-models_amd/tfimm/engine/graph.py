@@ -293,8 +293,14 @@ class Builder:
              bn_eps=1e-5, bias: Optional[str] = None, act="", residual: Optional[TRef] = None,
              act_after_res=False, a_scale: Optional[TRef] = None, flatten=False,
              remap=None, res_const=None, res_mod=0, then_maxpool=None, flops_k: Optional[int] = None,
-             cite="", name="") -> TRef:
+             fold_shortcut=None, cite="", name="") -> TRef:
         """Conv2D (+ZeroPadding2D / "same") + folded BN / bias + activation + residual.
+
+        ``fold_shortcut=(x2, kernel2, bn2, stride2)``: this is the last 1x1 convolution of a residual block whose shortcut
+        is ``bn2(conv1x1_stride2(x2))`` (resnet.py:282-290, 315-330): instead of a launch that writes the shortcut tensor and
+        a ``residual`` operand that reads it back, the shortcut's input channels become further k-tiles of THIS GEMM
+        (tfimm_gemm_desc::a2; ``can_fold_shortcut`` says when: channel counts of both operands and of the output multiples of 8) -- ``act`` is then the
+        block's final activation.
 
         ``padding``: int (symmetric, as the reference's ZeroPadding2D + VALID), "same"
         (TF asymmetric, layers/conv.py:61) or an explicit ``((top, bottom), (left, right))``.
@@ -368,6 +374,19 @@ class Builder:
             wt, bvec = pack.pack_dense(k.reshape(cin, cout) * (1.0 if scale is None else scale.reshape(1, cout)), shift,
                                        fp32=self.fp32)
             attrs.update(mode=0, K=cin, lda=x.C, a_rows_per_image=x.rows)
+            if fold_shortcut is not None:
+                x2, kernel2, bn2, stride2 = fold_shortcut
+                assert self.can_fold_shortcut(x2, stride2, cout, cin) and residual is None and a_scale is None and remap is None
+                k2 = self.wget(kernel2)
+                assert k2.shape[:2] == (1, 1) and k2.shape[2] == x2.C and k2.shape[3] == cout
+                oh2, ow2 = (x2.H - 1) // stride2 + 1, (x2.W - 1) // stride2 + 1        # 1x1 / stride s, no padding
+                assert (oh2, ow2) == (OH, OW), (oh2, ow2, OH, OW)
+                scale2, shift2 = self.bn(bn2, bn_eps)
+                wt2, _ = pack.pack_dense(k2.reshape(x2.C, cout) * scale2.reshape(1, cout), None)
+                wt = np.concatenate([wt, wt2], axis=1)          # [N][ceil64(K) + ceil64(K2)]: the second operand's k-tiles follow
+                bvec = shift2 if bvec is None else bvec + shift2
+                attrs["dual"] = dict(K2=x2.C, lda2=x2.C, stride=stride2, H=x2.H, W=x2.W, OH=OH, OW=OW)
+                attrs["K_true"] = cin + x2.C
         else:
             assert a_scale is None
             wt, bvec, kk, mode = pack.pack_conv(k, scale, shift, x.C, fp32=self.fp32)
@@ -392,10 +411,22 @@ class Builder:
         if remap is not None:
             # rows land in a larger token buffer: (rows_in_per_image, rows_out_per_image, offset)
             out.rows = remap[1]
+        if attrs.get("dual"):
+            ins.append(fold_shortcut[0])
+        else:
+            assert fold_shortcut is None, "fold_shortcut needs a 1x1 / stride-1 convolution (see can_fold_shortcut)"
         p.add("gemm", ins, out, consts, cite=cite, **attrs)
         if then_maxpool is not None:
             return self.maxpool(out, *then_maxpool, cite=cite)
         return out
+
+    def can_fold_shortcut(self, x2: TRef, stride2: int, cout: int, cin: int = 8) -> bool:
+        """Whether ``conv(..., fold_shortcut=(x2, ...))`` can take a 1x1 / stride-``stride2`` shortcut convolution of ``x2`` as a
+        second A operand: the bf16 product path on a library that has the entry (ABI >= 4), 16-byte aligned channel runs on
+        both sides.  TFIMM_NO_FOLD_SHORTCUT=1 keeps the shortcut a launch of its own (A/B)."""
+        from . import ffi
+        return (not self.fp32 and ffi.ABI >= 4 and x2.H > 0 and x2.W > 0 and x2.C % 8 == 0 and cout % 8 == 0 and cin % 8 == 0 and stride2 >= 1
+                and os.environ.get("TFIMM_NO_FOLD_SHORTCUT", "0") != "1")
 
     def conv_chain(self, x: TRef, kernel1: str, bn1: str, kernel2: str, bn2: str, *, stride=1, padding=1, bn_eps=1e-5,
                    act1="relu", act2="relu", residual: Optional[TRef] = None, shortcut_conv=None, cite="") -> Optional[TRef]:
@@ -1101,6 +1132,12 @@ class Plan:
                     d.rows_per_image = a["a_rows_per_image"]
                 if a.get("remap"):
                     d.remap_in, d.remap_out, d.remap_off = a["remap"]
+                if a.get("dual"):
+                    du = a["dual"]
+                    d.a2 = self.tptr(op.inputs[idx])
+                    idx += 1
+                    d.K2, d.lda2, d.a2_stride = du["K2"], du["lda2"], du["stride"]
+                    d.a2_H, d.a2_W, d.a2_OH, d.a2_OW = du["H"], du["W"], du["OH"], du["OW"]
                 d.tile_hint = tune.lookup(d)
                 self._keepalive.append(d)
                 self._gemm_descs.append(d)

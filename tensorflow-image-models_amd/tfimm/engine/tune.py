@@ -42,6 +42,8 @@ def key_of(d) -> str:
     key = ":".join(str(int(v)) for v in (
         d.mode, d.M, d.N, d.K, d.lda, d.ldc, d.H, d.W, d.Cin, d.KH, d.KW, d.stride,
         1 if d.residual else 0, d.out_f32, d.act, 1 if d.a_scale else 0))
+    if getattr(d, "a2", None):          # a second A operand (ABI v4): K2 more channels, read at a2_stride
+        key += f":d{int(d.K2)}s{int(d.a2_stride)}"
     return key + ":ln" if getattr(d, "ln_stats", None) else key
 
 
@@ -66,7 +68,14 @@ def strip_shape(d) -> bool:
             and getattr(d, "ldw", d.K) >= d.K and pitch == 128 and d.ldc % 8 == 0)
 
 
+# a layer with a second A operand runs on the persistent tiles only (28 = the deep-ring schedule and 30 = the duo kernel have no
+# such flavour: the library answers them with another tile)
+DUAL_CANDIDATES = (0, 21, 22, 23, 24, 25, 26, 27, 29)
+
+
 def candidates_for(d):
+    if getattr(d, "a2", None):
+        return DUAL_CANDIDATES
     if getattr(d, "ln_stats", None):
         return LN_CANDIDATES
     c = SCALE_CANDIDATES if getattr(d, "a_scale", None) else CANDIDATES

@@ -174,6 +174,41 @@ def _se_scale_case(B, R, K, N, seed, tile=0, residual=False, bias=False):
     return _err(_cpu(got), ref), TOL_BF16
 
 
+def _dual_case(B, OH, OW, K1, K2, N, stride, seed, tile=0, act="relu"):
+    """A second A operand (tfimm_gemm_desc::a2, ABI v4): conv3 of a bottleneck + its 1x1 / stride-s shortcut convolution as
+    ONE GEMM -- out = act(h . W3 + x[:, ::s, ::s] . Wds + b3 + bds)  (resnet.py:282-290, 315-330)."""
+    import hip_ops as H
+    r = _rng(seed)
+    H2, W2 = (OH - 1) * stride + 1 + (stride > 1), (OW - 1) * stride + 1 + (stride > 1)      # an even-sized input for stride 2
+    M = B * OH * OW
+    h = _bf(r.standard_normal((M, K1)))
+    x = _bf(r.standard_normal((B, H2, W2, K2)))
+    w3 = _bf(r.standard_normal((K1, N)) / math.sqrt(K1))
+    wd = _bf(r.standard_normal((K2, N)) / math.sqrt(K2))
+    bvec = r.standard_normal(N).astype(np.float32)
+    xs = x[:, ::stride, ::stride, :][:, :OH, :OW, :].reshape(M, K2)
+    ref = h.astype(np.float64) @ w3.astype(np.float64) + xs.astype(np.float64) @ wd.astype(np.float64) + bvec
+    if act == "relu":
+        ref = np.maximum(ref, 0.0)
+    k1p, k2p = -(-K1 // 64) * 64, -(-K2 // 64) * 64
+    wt = np.zeros((N, k1p + k2p), np.float32)
+    wt[:, :K1] = w3.T
+    wt[:, k1p:k1p + K2] = wd.T
+    got = H.gemm(H.dev_bf16(h), H.dev_bits(pack.to_bf16_bits(wt)), N, K1, bias=H.dev_f32(bvec), act=act, tile_hint=tile,
+                 a2=H.dev_bf16(x.reshape(-1, K2)), a2_geom=None if stride == 1 else (stride, H2, W2, OH, OW))
+    H.sync()
+    return _err(_cpu(got), ref), TOL_BF16
+
+
+# ResNet-50's three strided first blocks at small batch (stage 2: 128 + 256 -> 512 at 28 x 28; stage 3: 256 + 512 -> 1024; stage 4)
+CASES["gemm_dual_resnet_stage2_s2"] = lambda: _dual_case(3, 28, 28, 128, 256, 512, 2, 140)
+CASES["gemm_dual_resnet_stage3_s2"] = lambda: _dual_case(5, 14, 14, 256, 512, 1024, 2, 141)
+CASES["gemm_dual_resnet_stage4_s2"] = lambda: _dual_case(6, 7, 7, 512, 1024, 2048, 2, 142)
+CASES["gemm_dual_stride1_ragged_k"] = lambda: _dual_case(2, 9, 11, 72, 40, 96, 1, 143, act="")        # K1, K2 not whole k-tiles; M = 198
+for _t in (21, 22, 23, 24, 25, 26, 27, 29, 30):
+    CASES[f"gemm_dual_tile{_t}"] = lambda t=_t: _dual_case(4, 14, 14, 192, 136, 264, 2, 150 + t, tile=t)   # N % 8 == 0 only, two column tiles at 256
+
+
 CASES["gemm_se_scale_prologue"] = lambda: _se_scale_case(3, 50, 48, 24, 20)
 for _t in (1, 21, 22, 23, 24, 25, 26, 27, 29):
     # rows_per_image 144 < tile height: a tile spans 2-3 images; K = 200 is not a whole k-tile / gate piece

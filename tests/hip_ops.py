@@ -46,8 +46,10 @@ def ptr(t):
 
 def gemm(a, wt, N, K, *, M=None, bias=None, residual=None, out=None, act="", act_after_res=False,
          out_f32=False, lda=None, ldc=None, ldr=None, res_mod=0, remap=None, conv=None, a_scale=None,
-         rows_per_image=0, tile_hint=0, out_rows=None, a_byte_offset=0, out_byte_offset=0, ln_stats=None, ln_c1=None):
-    """conv: dict(mode, B, H, W, Cin, KH, KW, stride, pad_t, pad_l, OH, OW)."""
+         rows_per_image=0, tile_hint=0, out_rows=None, a_byte_offset=0, out_byte_offset=0, ln_stats=None, ln_c1=None,
+         a2=None, a2_geom=None):
+    """conv: dict(mode, B, H, W, Cin, KH, KW, stride, pad_t, pad_l, OH, OW).
+    a2: second A operand [rows2][K2] (tfimm_gemm_desc::a2); a2_geom = (stride, H, W, OH, OW) for a strided row view."""
     d = ffi.GemmDesc()
     if conv is None:
         M = M if M is not None else a.shape[0]
@@ -86,6 +88,11 @@ def gemm(a, wt, N, K, *, M=None, bias=None, residual=None, out=None, act="", act
         d.rows_per_image = rows_per_image
     if ln_stats is not None:
         d.ln_stats, d.ln_c1 = ptr(ln_stats), ptr(ln_c1)
+    if a2 is not None:
+        d.a2, d.K2, d.lda2 = ptr(a2), a2.shape[-1], a2.shape[-1]
+        d.a2_stride = 1
+        if a2_geom is not None:
+            d.a2_stride, d.a2_H, d.a2_W, d.a2_OH, d.a2_OW = a2_geom
     if tile_hint == "table":        # what the engine would launch for this shape (tfimm/engine/gemm_tune.json)
         from tfimm.engine import tune
         tile_hint = tune.lookup(d)
