@@ -1,6 +1,7 @@
 """CPU: the GEMM tile table (tfimm/engine/tune.py, gemm_tune.json) -- key format, hint ranges, LayerNorm-folded layers keyed apart."""
 import json
 import os
+import re
 
 from tfimm.engine import ffi, tune
 
@@ -25,6 +26,8 @@ def test_key_covers_shape_epilogue_and_ln_flavour():
     ln = tune.key_of(_desc(ln_stats=0x1000, ln_c1=0x2000))
     assert ln == base + ":ln"                                             # same shape, other kernel flavour: own entry
     assert tune.key_of(_desc(M=100865)) != base
+    dual = tune.key_of(_desc(a2=0x1000, K2=256, a2_stride=2))
+    assert dual == base + ":d256s2" and tune.candidates_for(_desc(a2=0x1000, K2=256, a2_stride=2)) == tune.DUAL_CANDIDATES
 
 
 def test_committed_table_is_well_formed():
@@ -33,6 +36,10 @@ def test_committed_table_is_well_formed():
     valid = {0} | set(range(1, 7)) | set(range(11, 17)) | set(range(21, 32))
     for key, hint in table.items():
         fields = key[:-3].split(":") if key.endswith(":ln") else key.split(":")
+        dual = re.fullmatch(r"d(\d+)s(\d+)", fields[-1])      # a second A operand (ABI v4): ":d<K2>s<stride>"
+        if dual:
+            fields = fields[:-1]
+            assert hint in tune.DUAL_CANDIDATES and fields[0] == "0" and int(dual.group(1)) % 8 == 0, (key, hint)
         assert len(fields) == 16 and all(f.lstrip("-").isdigit() for f in fields), key
         assert hint in valid, (key, hint)
         if hint == 31:      # the input-strip kernel: 3x3 / stride 1 convolutions of 128 -> 128 channels, rows of at most 31 pixels
