@@ -31,7 +31,10 @@ def op_bytes_flops(op, prog, B):
         byts = a_bytes + N * a["ldw"] * 2 + M * N * (4 if a["out_f32"] else 2)
         if a.get("has_residual"):
             byts += M * N * 2
-        return byts, 2.0 * M * N * K, f"M={M} K={a['K']} N={N} mode={a['mode']}" + \
+        du = a.get("dual")
+        if du:          # a second A operand (the block's shortcut convolution): its strided rows and its weights
+            byts += M * du["K2"] * 2 + N * du["K2"] * 2
+        return byts, 2.0 * M * N * K, f"M={M} K={a['K']}{('+' + str(du['K2']) + '/s' + str(du['stride'])) if du else ''} N={N} mode={a['mode']}" + \
             (f" {a['KH']}x{a['KW']}s{a['stride']} {a['H']}->{a['OH']}" if a["mode"] else "") + \
             (" +res" if a.get("has_residual") else "") + (f" {a['act']}" if a["act"] else "")
     if k == "stem_pool":
