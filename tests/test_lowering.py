@@ -333,3 +333,37 @@ def test_live_tensors_across_a_cut_and_branch_support():
     assert prog.supports_branches()
     _, cait = _kinds("cait_test_model")
     assert cait.supports_branches()          # round 4: the talking-heads kernel is reproducible next to other launches
+
+
+def _duals(prog):
+    return [op for op in prog.ops if op.kind == "gemm" and op.attrs.get("dual")]
+
+
+def test_strided_shortcut_convolutions_become_a_second_operand_of_conv3(monkeypatch):
+    """resnet.py:282-290 + 315-330: the 1x1 / stride-2 `downsample` convolution of the first block of stages 2 - 4 is folded into
+    that block's conv3 (tfimm_gemm_desc::a2): three launches and three shortcut tensors fewer, same FLOPs; the stage-1 case
+    stays with the chain kernel's own shortcut flavour."""
+    kinds, prog = _kinds("resnet50")
+    d = _duals(prog)
+    assert len(prog.ops) == 46 and len(d) == 3
+    assert [(o.attrs["K"], o.attrs["dual"]["K2"], o.attrs["N"], o.attrs["dual"]["stride"]) for o in d] == [
+        (128, 256, 512, 2), (256, 512, 1024, 2), (512, 1024, 2048, 2)]
+    for o in d:
+        du = o.attrs["dual"]
+        assert (du["H"], du["W"]) == (2 * du["OH"], 2 * du["OW"]) and o.attrs["act"] == "relu" and not o.attrs.get("has_residual")
+        assert o.attrs["ldw"] == -(-o.attrs["K"] // 64) * 64 + -(-du["K2"] // 64) * 64         # both parts padded to whole k-tiles
+        assert len(o.inputs) == 2 and prog.tensors[o.inputs[1]].C == du["K2"]
+    assert abs(prog.flops_per_image() / 1e9 - 8.178) < 0.01
+    monkeypatch.setenv("TFIMM_NO_FOLD_SHORTCUT", "1")
+    kinds, plain = _kinds("resnet50")
+    assert len(plain.ops) == 49 and not _duals(plain) and abs(plain.flops_per_image() - prog.flops_per_image()) < 1
+
+
+@pytest.mark.parametrize("name,n", [("resnext50_32x4d", 3), ("wide_resnet50_2", 3), ("resnet101", 3),
+                                    ("seresnet50", 0),      # the SE gate sits between conv3 and the add
+                                    ("resnet50d", 0),       # average-pool shortcut: a 2 x 2 gather, not a 1 x 1 convolution
+                                    ("resnet18", 0),        # basic blocks: the last convolution is a 3 x 3 gather
+                                    ("resnet50_gn", 0)])    # GroupNorm does not fold into the weights
+def test_which_configurations_fold_their_shortcut(name, n):
+    _, prog = _kinds(name)
+    assert len(_duals(prog)) == n
