@@ -159,3 +159,16 @@ def test_dp_header_symbols_exported_and_shard_bounds_without_gpu():
     assert lib.tfimm_hip_dp_forward(None, None, None, 0, None, 0, None, None) == -1
     assert lib.tfimm_hip_dp_unique_id(None, 0) == -1
     assert lib.tfimm_hip_dp_destroy(None) == 0
+
+
+def test_the_documented_binding_mirrors_the_gemm_descriptor():
+    """INTEGRATION.md shows the ctypes stub a tfimm maintainer would add; its GemmDesc must have the library's layout (a stub that
+    stops short of the struct's end makes the library read whatever follows it in memory)."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index("class GemmDesc(C.Structure):"):doc.index("_lib.tfimm_hip_gemm.argtypes")]
+    ns = {"C": ctypes}
+    exec(block, ns)                                                   # the documented class itself
+    stub = ns["GemmDesc"]
+    assert [f[0] for f in stub._fields_] == [f[0] for f in ffi.GemmDesc._fields_]
+    assert ctypes.sizeof(stub) == ctypes.sizeof(ffi.GemmDesc)
+    assert f"abi_version() == {ffi.ABI}" in doc
