@@ -934,6 +934,202 @@ __global__ void __launch_bounds__(256) attn_window_kernel(const AttnArgs p, cons
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same, with the (relative-position bias + shift mask) tile out of the window loop (round 6).  In attn_window_kernel every
+// (window, head) loads its 16 bias values per lane again -- 16 KB per head and workgroup against 9.4 KB of Q, K and V: at
+// Swin-B's stage 1 (65536 windows x 4 heads per layer) that is 4.3 GB of L2 reads per launch next to 0.6 GB of activations,
+// and the launch runs at the L2's rate, not at HBM's.  The tile depends on the head and on the window's mask KIND only
+// (interior / right edge / bottom edge / corner of the shifted frame, swin.py:243-285): a workgroup now owns HPW heads and
+// a CHUNK of consecutive windows of ONE kind, holds its bias values in registers (16 x HPW floats per lane, loaded once) and
+// walks the windows.  Same arithmetic per (window, head) as attn_window_kernel -- bit-identical results.
+// Kinds of one image's nwy x nwx windows (shift > 0): 0 = wy < nwy-1 and wx < nwx-1, 1 = right column, 2 = bottom row,
+// 3 = corner; shift == 0: every window is kind 0.
+struct WinSched {
+  int cnt[4];       // windows of each kind per image
+  int first[5];     // first chunk of each kind in the chunk list (first[4] = number of chunks)
+  int wpb;          // windows per chunk
+};
+
+template <int HD, int HPW>
+__global__ void __launch_bounds__(256) attn_window_persist_kernel(const AttnArgs p, const int hsplit, const WinSched ws) {
+  constexpr int NT = 256;
+  constexpr int CH = HD / 8, KROW = CH + 1, DT = HD / 16;
+  static_assert(HD == 32 && NT == 64 * CH, "window kernel: head dim 32, one K and one V chunk per thread");
+  constexpr int NKP = 64;
+  constexpr float LOG2E = 1.4426950408889634f;
+  __shared__ __attribute__((aligned(16))) uint4 Ks[NKP * KROW];
+  __shared__ __attribute__((aligned(16))) uint4 Vs[NKP * CH];
+  __shared__ int Rw[2 * NKP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  int item = blockIdx.x;
+  {   // XCD-contiguous ranges
+    const int G = (int)gridDim.x, xcd = item & 7, idx = item >> 3;
+    item = xcd * (G >> 3) + min(xcd, G & 7) + idx;
+  }
+  const int cg = item / hsplit, part = item - cg * hsplit;
+  const int h0 = part * HPW;
+  const int kind = cg >= ws.first[3] ? 3 : cg >= ws.first[2] ? 2 : cg >= ws.first[1] ? 1 : 0;
+  const int cnt = ws.cnt[kind];
+  const int j0 = (cg - ws.first[kind]) * ws.wpb;                 // first window of this chunk in the kind's list
+  const int j1 = min(j0 + ws.wpb, p.batch * cnt);
+  const int nwy = p.nw / p.nwx;
+
+  const int qi = wave * 16 + l15;
+  const bool q_ok = qi < p.n;
+  const int skey = tid / CH, sc8 = tid - skey * CH;
+  const bool s_ok = skey < p.n;
+  const float cs = p.scale * LOG2E;
+
+  // this lane's bias values of its HPW heads: once per workgroup
+  float4 bias[HPW][4];
+  {
+    const float* bbase = p.bias_log2 + ((size_t)(p.shift > 0 ? kind : 0) * p.heads * p.n + (q_ok ? qi : 0)) * NKP + g * 4;
+#pragma unroll
+    for (int hl = 0; hl < HPW; ++hl)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bias[hl][t] = *reinterpret_cast<const float4*>(bbase + (size_t)(h0 + hl) * p.n * NKP + t * 16);
+  }
+
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  // window j of this kind -> (image, wy, wx) -> sequence index
+  auto seq_of = [&](int j) __attribute__((always_inline)) -> int {
+    const int b = j / cnt, r = j - b * cnt;
+    int wy, wx;
+    if (p.shift == 0 || kind == 0) {
+      const int rowlen = p.shift == 0 ? p.nwx : p.nwx - 1;
+      wy = r / rowlen; wx = r - wy * rowlen;
+    } else if (kind == 1) { wy = r; wx = p.nwx - 1; }
+    else if (kind == 2) { wy = nwy - 1; wx = r; }
+    else { wy = nwy - 1; wx = p.nwx - 1; }
+    return b * p.nw + wy * p.nwx + wx;
+  };
+  // The loads run ONE HEAD AHEAD across window boundaries as well: the index map of window j + 1 is computed while window j is
+  // being multiplied (second buffer of Rw, published by window j's barriers), and the first head of window j + 1 is requested
+  // under the arithmetic of window j's last head.
+  u32x4 kreg, vreg, qreg;
+  const bf16_t *srow, *qrow;
+  int64_t q_row;
+  auto bind = [&](const int* rw) __attribute__((always_inline)) {
+    q_row = rw[q_ok ? qi : 0];
+    srow = p.qkv + (int64_t)rw[s_ok ? skey : 0] * p.ld + sc8 * 8;
+    qrow = p.qkv + q_row * p.ld + g * 8;
+  };
+  auto fetch = [&](int h) __attribute__((always_inline)) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    kreg = s_ok ? *reinterpret_cast<const u32x4*>(srow + p.dmodel + h * HD) : z;
+    vreg = s_ok ? *reinterpret_cast<const u32x4*>(srow + 2 * p.dmodel + h * HD) : z;
+    qreg = q_ok ? *reinterpret_cast<const u32x4*>(qrow + h * HD) : z;
+  };
+  if (j0 < j1) {
+    if (tid < NKP) {
+      int rg;
+      Rw[tid] = tid < p.n ? (int)token_row<true>(p, seq_of(j0), tid, &rg) : 0;
+    }
+    __syncthreads();
+    bind(Rw);
+    fetch(h0);
+  }
+  int cur = 0;
+  for (int j = j0; j < j1; ++j, cur ^= 1) {
+    const int64_t q_row_cur = q_row;            // (bind() below moves q_row to the next window while this one is being stored)
+    if (j + 1 < j1 && tid < NKP) {               // next window's index map: read behind this window's barriers
+      int rg;
+      Rw[(cur ^ 1) * NKP + tid] = tid < p.n ? (int)token_row<true>(p, seq_of(j + 1), tid, &rg) : 0;
+    }
+#pragma unroll
+    for (int hl = 0; hl < HPW; ++hl) {
+      const int h = h0 + hl;
+      reinterpret_cast<u32x4*>(Ks)[k_slot<HD>(skey, sc8)] = kreg;
+      reinterpret_cast<u32x4*>(Vs)[v_slot<HD>(skey, sc8)] = vreg;
+      const bf16x8 qf = __builtin_bit_cast(bf16x8, qreg);
+      __syncthreads();
+      if (hl + 1 < HPW) fetch(h + 1);                 // in flight under this head's arithmetic
+      else if (j + 1 < j1) {                          // ... the next window's first head under this window's last
+        bind(Rw + (cur ^ 1) * NKP);
+        fetch(h0);
+      }
+      if (wave * 16 < p.n) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          const bf16x8 kf = __builtin_bit_cast(bf16x8, Ks[k_slot<HD>(t * 16 + l15, g)]);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, acc[t], 0, 0, 0);
+        }
+        float sc[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float4 b4 = bias[hl][t];
+          sc[t * 4 + 0] = fmaf(acc[t][0], cs, b4.x); sc[t * 4 + 1] = fmaf(acc[t][1], cs, b4.y);
+          sc[t * 4 + 2] = fmaf(acc[t][2], cs, b4.z); sc[t * 4 + 3] = fmaf(acc[t][3], cs, b4.w);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr)
+            if (t * 16 + g * 4 + rr >= p.n) sc[t * 4 + rr] = -__builtin_inff();
+        float mloc = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) mloc = fmaxf(fmaxf(mloc, sc[i]), sc[i + 1]);
+        mloc = fmaxf(mloc, sc[15]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          sc[i] = __builtin_amdgcn_exp2f(sc[i] - mloc);
+          psum += sc[i];
+        }
+        bf16x8 pf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          uint4 pu;
+          pu.x = pack_bf2(sc[8 * s2 + 0], sc[8 * s2 + 1]);
+          pu.y = pack_bf2(sc[8 * s2 + 2], sc[8 * s2 + 3]);
+          pu.z = pack_bf2(sc[8 * s2 + 4], sc[8 * s2 + 5]);
+          pu.w = pack_bf2(sc[8 * s2 + 6], sc[8 * s2 + 7]);
+          pf[s2] = __builtin_bit_cast(bf16x8, pu);
+        }
+        f32x4 o[DT];
+#pragma unroll
+        for (int i = 0; i < DT; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        typedef __attribute__((ext_vector_type(4))) short s16x4;
+        typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const int krow = g * 4 + (l15 >> 2);
+            const int chunk = dt * 2 + ((l15 & 3) >> 1);
+            const char* base = reinterpret_cast<const char*>(Vs) + (l15 & 1) * 8;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (lds_s16x4_ptr)(base + (size_t)v_slot<HD>(krow + (2 * s2) * 16, chunk) * 16));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (lds_s16x4_ptr)(base + (size_t)v_slot<HD>(krow + (2 * s2 + 1) * 16, chunk) * 16));
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            const s16x8 cat = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cat), pf[s2], o[dt], 0, 0, 0);
+          }
+        }
+        float l_tot = psum + __shfl_xor(psum, 16, 64);
+        l_tot += __shfl_xor(l_tot, 32, 64);
+        if (q_ok) {
+          const float inv = 1.f / l_tot;
+          bf16_t* op = p.out + q_row_cur * p.dmodel + h * HD;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const int d0 = dt * 16 + g * 4;
+            *reinterpret_cast<uint2*>(op + d0) =
+                make_uint2(pack_bf2(o[dt][0] * inv, o[dt][1] * inv), pack_bf2(o[dt][2] * inv, o[dt][3] * inv));
+          }
+        }
+      }
+      __syncthreads();                              // every wave is done with this head's K / V (and with Rw on the last head)
+    }
+  }
+}
+
 template <int HD, int NW, int TQ>
 static int launch_attn_stream(const AttnArgs& a, int64_t nseq, hipStream_t st) {
   const int nkp = (a.n + 63) / 64 * 64;
@@ -1053,6 +1249,36 @@ extern "C" int tfimm_hip_attention(const tfimm_attn_desc* dp, void* stream) {
     if (use_resident && !no_window && tl && a.vec && d.hd == 32 && a.n <= 64 && nseq * d.heads <= 0x7fffffffLL) {
       // heads per workgroup: split a window's heads over workgroups until there are ~16 workgroups per CU (measured on Swin-B:
       // 2.00 ms of attention at a 1024-workgroup threshold, 1.93 at 4096)
+      // (round 6) bias tiles out of the window loop: a workgroup owns HPW heads and a chunk of windows of one mask kind
+      // (attn_window_persist_kernel); TFIMM_ATTN_WIN_V1=1 keeps the one-window-per-workgroup kernel (A/B)
+      static const bool win_v1 = getenv("TFIMM_ATTN_WIN_V1") != nullptr;
+      if (!win_v1) {
+        const int hpw = (d.heads % 2 == 0) ? 2 : 1;
+        const int hsplit2 = d.heads / hpw;
+        const int nwy = a.nw / a.nwx;
+        WinSched ws;
+        if (d.shift > 0) {
+          ws.cnt[0] = (nwy - 1) * (a.nwx - 1); ws.cnt[1] = nwy - 1; ws.cnt[2] = a.nwx - 1; ws.cnt[3] = 1;
+        } else {
+          ws.cnt[0] = a.nw; ws.cnt[1] = ws.cnt[2] = ws.cnt[3] = 0;
+        }
+        // windows per chunk: as many as leave ~4096 workgroups (16 per CU), at most 16
+        static const int64_t win_wgs2 = getenv("TFIMM_ATTN_WIN_WGS") ? atoi(getenv("TFIMM_ATTN_WIN_WGS")) : 4096;
+        int64_t wpb = nseq * hsplit2 / win_wgs2;
+        wpb = wpb < 1 ? 1 : (wpb > 16 ? 16 : wpb);
+        ws.wpb = (int)wpb;
+        int64_t total = 0;
+        for (int k = 0; k < 4; ++k) {
+          ws.first[k] = (int)total;
+          total += ((int64_t)d.batch * ws.cnt[k] + wpb - 1) / wpb;
+        }
+        ws.first[4] = (int)total;
+        if (total * hsplit2 <= 0x7fffffffLL) {
+          if (hpw == 2) TFIMM_LAUNCH((attn_window_persist_kernel<32, 2>), dim3((unsigned)(total * hsplit2)), dim3(256), 0, st, a, hsplit2, ws);
+          else TFIMM_LAUNCH((attn_window_persist_kernel<32, 1>), dim3((unsigned)(total * hsplit2)), dim3(256), 0, st, a, hsplit2, ws);
+          return 0;
+        }
+      }
       int hsplit = 1;
       static const int64_t win_wgs = getenv("TFIMM_ATTN_WIN_WGS") ? atoi(getenv("TFIMM_ATTN_WIN_WGS")) : 4096;
       while (hsplit < d.heads && nseq * hsplit < win_wgs && d.heads % (hsplit * 2) == 0) hsplit *= 2;

@@ -625,6 +625,11 @@ CASES["swin_tiles_w7_shift3_21x35"] = lambda: _swin_case(2, 21, 35, 3, 32, 7, 3,
 CASES["swin_tiles_w4_shift2_8x8_hd4"] = lambda: _swin_case(2, 8, 8, 1, 4, 4, 2, 80, tiles=True)
 CASES["swin_tiles_w12_shift6_24x24"] = lambda: _swin_case(1, 24, 24, 2, 32, 12, 6, 81, tiles=True)
 CASES["swin_tiles_w7_shift3_single_row"] = lambda: _swin_case(2, 7, 21, 2, 32, 7, 3, 82, tiles=True)
+# (round 6: attn_window_persist_kernel -- chunks of windows of one mask kind, bias in registers)
+CASES["swin_tiles_w7_shift3_56x56_b5_chunks"] = lambda: _swin_case(5, 56, 56, 4, 32, 7, 3, 83, tiles=True)     # 320 windows x 2 head pairs: chunks of several windows, all four kinds
+CASES["swin_tiles_w7_noshift_56x56_b5_chunks"] = lambda: _swin_case(5, 56, 56, 4, 32, 7, 0, 84, tiles=True)
+CASES["swin_tiles_w7_shift3_3heads_odd"] = lambda: _swin_case(3, 28, 28, 3, 32, 7, 3, 85, tiles=True)           # Swin-T's stage 1: odd head count -> one head per workgroup
+CASES["swin_tiles_w7_shift3_single_col"] = lambda: _swin_case(2, 21, 7, 2, 32, 7, 3, 86, tiles=True)
 # persistent global-attention kernel (>= 2048 (image, head) items, 129..256 tokens, head dim 64): several items per
 # workgroup, the last round ragged; 197 / 256 / 129 tokens
 CASES["attn_stream_197_hd64"] = lambda: _attn_case(171, 197, 12, 64, 160)
