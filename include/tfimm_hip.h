@@ -129,7 +129,8 @@ typedef struct tfimm_gemm_desc {
                              ROUNDED weights and bias = beta . W + b.  The normalised tensor is never written. */
   const void* ln_c1;      /* bf16 [N][2][8]: c1[n] as the three-term bf16 split (ca, cb, cc), laid out as the MFMA fragment
                              pair {ca,cb,cc,ca,cb,cc,ca,cb} {cc,0,0,0,0,0,0,0} (tfimm/engine/pack.py: pack_ln_c1) */
-  /* ---- ABI v4: a SECOND A operand whose product accumulates into the same output tile (dense mode, no residual):
+  /* ---- ABI v4: a SECOND A operand whose product accumulates into the same output tile (mode TFIMM_A_DENSE or TFIMM_A_CONV for
+   *      the first operand -- the 1x1 conv3 of a bottleneck, the 3x3 conv2 of a basic block -- no residual):
    *      out = act( a . wt[:, 0:K]^T + a2' . wt[:, Kp:Kp+K2]^T + bias ),   Kp = K rounded up to 64.
    * It is the shortcut convolution of a residual block folded into the block's last 1x1 convolution (resnet.py:282-290
    * `x = self.conv3(x) ... shortcut = self.downsample(shortcut) ... x += shortcut`, downsample_conv resnet.py:315-330: a 1x1

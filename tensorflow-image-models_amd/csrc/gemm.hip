@@ -201,8 +201,8 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
 
   if (d.a2) {
     // second A operand (ABI v4): the shortcut convolution of a residual block as further k-tiles of this GEMM
-    if (d.mode != TFIMM_A_DENSE || d.residual || d.a_scale || d.ln_stats || d.out_f32 || d.remap_in || d.res_mod)
-      TFIMM_FAIL(TFIMM_EINVAL, "gemm: a second A operand needs a dense bf16 layer without residual / gate / LayerNorm / row remap");
+    if ((d.mode != TFIMM_A_DENSE && d.mode != TFIMM_A_CONV) || d.residual || d.a_scale || d.ln_stats || d.out_f32 || d.remap_in || d.res_mod)
+      TFIMM_FAIL(TFIMM_EINVAL, "gemm: a second A operand needs a bf16 layer (dense or TFIMM_A_CONV) without residual / gate / LayerNorm / row remap");
     if (d.K2 <= 0 || (d.K2 & 7) || d.lda2 < d.K2 || (d.lda2 & 7) || ((uintptr_t)d.a2 & 15))
       TFIMM_FAIL(TFIMM_EINVAL, "gemm: a2 needs K2=%d %% 8 == 0, lda2=%d >= K2 and %% 8 == 0, a 16-byte aligned pointer", d.K2, d.lda2);
     if (d.a2_stride < 1) TFIMM_FAIL(TFIMM_EINVAL, "gemm: a2_stride=%d", d.a2_stride);
@@ -295,7 +295,7 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
   //      hint keeps the implicit-GEMM tiles (the tuner's candidates).
   if (kmode == K_CONV && d.KH == 3 && d.KW == 3 && d.stride == 1 && g.stride_w == 1 && d.pad_t == 1 && d.pad_l == 1 && d.OH == d.H &&
       d.OW == d.W && d.Cin == 128 && g.cpitch == 128 && d.N == 128 && !d.residual && !d.out_f32 && g.out_vec16 && d.remap_in == 0 &&
-      !d.ln_stats && d.W <= 31 && d.ldw >= d.K && (d.tile_hint == 31 || (d.tile_hint == 0 && strip_conv_enabled() && cdiv64(d.M, 128) >= num_cu()))) {
+      !d.ln_stats && !d.a2 && d.W <= 31 && d.ldw >= d.K && (d.tile_hint == 31 || (d.tile_hint == 0 && strip_conv_enabled() && cdiv64(d.M, 128) >= num_cu()))) {
     const int64_t a_bytes = ((int64_t)d.B * d.H * d.W) * 128 * 2, w_bytes = (int64_t)d.N * d.ldw * 2;
     const int64_t out_bytes = ((int64_t)(d.M - 1) * d.ldc + d.N) * 2;
     if (a_bytes <= 0x7fffff00LL && w_bytes <= 0x7fffff00LL && out_bytes <= 0x7fffff00LL)
@@ -320,7 +320,7 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
     const bool ok = (kmode == K_DENSE || kmode == K_CONV || scale) && (!hinted_other || dual) && !stream_disabled() && !dma_disabled() &&
                     d.ldw >= (int)(cdiv64(d.K, 64) * 64) && a_bytes <= 0x7fffff00LL && w_bytes <= 0x7fffff00LL &&
                     out_bytes <= 0x7fffff00LL && res_bytes <= 0x7fffff00LL && a2_bytes <= 0x7fffff00LL &&
-                    (!dual || (kmode == K_DENSE && d.ldw >= (int)(cdiv64(d.K, 64) * 64 + cdiv64(d.K2, 64) * 64)));
+                    (!dual || ((kmode == K_DENSE || kmode == K_CONV) && d.ldw >= (int)(cdiv64(d.K, 64) * 64 + cdiv64(d.K2, 64) * 64)));
     if (ok) {
       const int fi = kmode == K_CONV ? 1 : 0;
       // vector epilogue: whole 16-byte groups per lane on aligned rows
@@ -364,7 +364,7 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       }
       if (dual) {
         if (ei != 2) TFIMM_FAIL(TFIMM_EUNSUP, "gemm: a second A operand needs N %% 8 == 0 and 16-byte aligned bf16 output rows");
-        if (!t->fn_dual) {
+        if (!t->fn_dual[fi]) {
           ti = 0;
           t = stream_tile_table(ti);
         }
@@ -456,12 +456,12 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
         return 0;
       }
       if (dual) {
-        static tfimm_once_t dual_attr[TFIMM_GEMM_STREAM_NUM_TILES];
-        if (dual_attr[ti].need()) {
-          TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)t->fn_dual, hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_bytes));
-          dual_attr[ti].mark();
+        static tfimm_once_t dual_attr[TFIMM_GEMM_STREAM_NUM_TILES][2];
+        if (dual_attr[ti][fi].need()) {
+          TFIMM_HIP_CHECK(hipFuncSetAttribute((const void*)t->fn_dual[fi], hipFuncAttributeMaxDynamicSharedMemorySize, t->lds_bytes));
+          dual_attr[ti][fi].mark();
         }
-        TFIMM_LAUNCH(t->fn_dual, dim3((unsigned)grid), dim3(t->threads), (size_t)t->lds_bytes, (hipStream_t)stream, ga);
+        TFIMM_LAUNCH(t->fn_dual[fi], dim3((unsigned)grid), dim3(t->threads), (size_t)t->lds_bytes, (hipStream_t)stream, ga);
         return 0;
       }
       if (!scale) {
@@ -495,7 +495,7 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
   }
 
   if (d.ln_stats) TFIMM_FAIL(TFIMM_EUNSUP, "gemm: LayerNorm folding needs the persistent LDS-DMA family (K-padded weights, 16-byte aligned rows)");
-  if (d.a2) TFIMM_FAIL(TFIMM_EUNSUP, "gemm: a second A operand needs the persistent LDS-DMA family (K %% 8 == 0, K-padded weights, 16-byte aligned rows)");
+  if (d.a2) TFIMM_FAIL(TFIMM_EUNSUP, "gemm: a second A operand needs the persistent LDS-DMA family (channel counts %% 8 == 0, K-padded weights, 16-byte aligned rows)");
   if (d.mode != TFIMM_A_DENSE && g.stride_w != g.stride)
     TFIMM_FAIL(TFIMM_EUNSUP, "gemm: stride_w != stride needs the persistent LDS-DMA family (Cin %% 8 == 0, 16-byte aligned input)");
 

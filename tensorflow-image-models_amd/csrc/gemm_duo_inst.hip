@@ -9,7 +9,7 @@ extern "C" __attribute__((visibility("hidden"))) const StreamTileCfg tfimm_gemm_
     {{nullptr, gemm_duo_kernel<K_DENSE, 0>, gemm_duo_kernel<K_DENSE, 1>},
      {nullptr, gemm_duo_kernel<K_CONV, 0>, gemm_duo_kernel<K_CONV, 1>}},
     {nullptr, nullptr, nullptr},
-    nullptr,                           // (no second-operand flavour)
+    {nullptr, nullptr},                // (no second-operand flavour)
     gemm_duo_kernel<K_DENSE, 2>,
     0};
 

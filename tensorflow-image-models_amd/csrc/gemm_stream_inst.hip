@@ -28,7 +28,8 @@ extern "C" __attribute__((visibility("hidden"))) const StreamTileCfg TFIMM_CAT(t
       gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_CONV, true, false, true>}},
     {gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_DENSE, false, true>, gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_DENSE, true, true>,
      gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_DENSE, true, true, true>},
-    gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_DENSE, true, false, true, false, true>,
+    {gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_DENSE, true, false, true, false, true>,
+     gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_CONV, true, false, true, false, true>},
     gemm_stream_kernel<T::bm, T::bn, T::wm, T::wn, K_DENSE, true, false, true, true>,
     G::NW * (1 + G::WTN / 32) * 1024};
 

@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   static_assert(WTN == 32 || WTN == 64, "epilogue swizzle is written for 32/64-wide wave tiles");
   static_assert(!SCALE || KMODE == K_DENSE, "the SE-gate prologue exists for dense rows");
   static_assert(!LNIN || (VEC && NORES && !SCALE && KMODE == K_DENSE), "LayerNorm folding: dense rows, residual-free vector epilogue");
-  static_assert(!DUAL || (VEC && NORES && !SCALE && !LNIN && KMODE == K_DENSE), "second A operand: dense rows, residual-free vector epilogue");
+  static_assert(!DUAL || (VEC && NORES && !SCALE && !LNIN), "second A operand: residual-free vector epilogue");
   constexpr int A_BYTES = G::A_BYTES, STAGE = G::STAGE;
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
@@ -193,17 +193,6 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
 #endif
         a_off[j] = ok ? (unsigned)(((size_t)msrc * p.lda + a_chunk(j) * 8) * 2) : kOobOffset;
         a_iy0[j] = a_ix0[j] = a_pix[j] = 0;
-        if (DUAL) {
-          int r2 = m;
-          if (pa.a2_stride > 1) {                      // (b, oy, ox) of the output row -> pixel (b, oy s, ox s) of the input image
-            const int mm = ok ? m : 0;
-            const int ohw = pa.a2_OH * pa.a2_OW;
-            const int b = mm / ohw, rem = mm - b * ohw;
-            const int oy = rem / pa.a2_OW, ox = rem - oy * pa.a2_OW;
-            r2 = (b * pa.a2_H + oy * pa.a2_stride) * pa.a2_W + ox * pa.a2_stride;
-          }
-          a_off2[j] = ok ? (unsigned)(((size_t)r2 * pa.lda2 + a_chunk(j) * 8) * 2) : kOobOffset;
-        }
       } else {
         const int mm = ok ? m : 0;
         const int ohw = p.OH * p.OW;
@@ -214,6 +203,17 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
         a_ix0[j] = ox * p.stride_w - p.pad_l;
         a_pix[j] = b * p.H * p.W;
         a_off[j] = 0;
+      }
+      if (DUAL) {        // the second operand is dense rows whatever the first one is (a gather for the 3 x 3 conv2 of a basic block)
+        int r2 = m;
+        if (pa.a2_stride > 1) {                      // (b, oy, ox) of the output row -> pixel (b, oy s, ox s) of the input image
+          const int mm = ok ? m : 0;
+          const int ohw = pa.a2_OH * pa.a2_OW;
+          const int b = mm / ohw, rem = mm - b * ohw;
+          const int oy = rem / pa.a2_OW, ox = rem - oy * pa.a2_OW;
+          r2 = (b * pa.a2_H + oy * pa.a2_stride) * pa.a2_W + ox * pa.a2_stride;
+        }
+        a_off2[j] = ok ? (unsigned)(((size_t)r2 * pa.lda2 + a_chunk(j) * 8) * 2) : kOobOffset;
       }
     }
 #pragma unroll
@@ -249,20 +249,19 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
       const int j = piece;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(sb + (wave * B_INSTR + j) * 1024), 16,
                                                (int)b_off[j], kbytes, 0, 0);
+    } else if (DUAL && kt >= nk1) {      // (wave-uniform) a k-tile of the second operand: dense rows
+      const int j = piece - B_INSTR;
+      const int kt2 = kt - nk1;
+      const bool kok = (kt2 * BK + a_chunk(j) * 8) < pa.K2;
+      const unsigned off = kok ? a_off2[j] : kOobOffset;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a2, (lds_ptr_t)(sa + (wave * A_INSTR + j) * 1024), 16,
+                                               (int)off, kt2 * 128, 0, 0);
     } else if (KMODE == K_DENSE) {
       const int j = piece - B_INSTR;
-      if (DUAL && kt >= nk1) {      // (wave-uniform) a k-tile of the second operand
-        const int kt2 = kt - nk1;
-        const bool kok = (kt2 * BK + a_chunk(j) * 8) < pa.K2;
-        const unsigned off = kok ? a_off2[j] : kOobOffset;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a2, (lds_ptr_t)(sa + (wave * A_INSTR + j) * 1024), 16,
-                                                 (int)off, kt2 * 128, 0, 0);
-      } else {
-        const bool kok = (kt * BK + a_chunk(j) * 8) < p.K;
-        const unsigned off = kok ? a_off[j] : kOobOffset;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sa + (wave * A_INSTR + j) * 1024), 16,
-                                                 (int)off, kbytes, 0, 0);
-      }
+      const bool kok = (kt * BK + a_chunk(j) * 8) < p.K;
+      const unsigned off = kok ? a_off[j] : kOobOffset;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sa + (wave * A_INSTR + j) * 1024), 16,
+                                               (int)off, kbytes, 0, 0);
     } else {
       const int j = piece - B_INSTR;
       int ky, kx, ci;
@@ -287,7 +286,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   };
   // after the last piece of a step: advance the scalar tap state of the NHWC gather
   auto issue_done = [&]() __attribute__((always_inline)) {
-    if (KMODE == K_CONV && pa.cin64) {
+    if (KMODE == K_CONV && pa.cin64) {        // (DUAL: the steps behind the last filter tap run past it harmlessly -- setup_issue resets the state per tile)
       s_ci0 += BK;
       if (s_ci0 >= p.Cin) {
         s_ci0 = 0;
@@ -822,7 +821,7 @@ struct StreamTileCfg {
   int bm, bn, threads, lds_bytes;
   gemm_stream_fn fn[2][3];     // [K_DENSE, K_CONV][catch-all, VEC, VEC without residual]
   gemm_stream_fn fn_scale[3];  // K_DENSE + SE gate on A, same three epilogues (null: not built for this tile)
-  gemm_stream_fn fn_dual;      // K_DENSE + a second A operand, residual-free vector epilogue (null: not built for this tile)
+  gemm_stream_fn fn_dual[2];   // [K_DENSE, K_CONV] + a second dense A operand, residual-free vector epilogue (null: not built for this tile)
   gemm_stream_fn fn_ln;        // K_DENSE, VEC without residual, LayerNorm folded in (LNIN); needs ln_lds extra bytes of LDS
   int ln_lds;
 };

@@ -287,10 +287,10 @@ class ResNet(Model):
                             and os.environ.get("TFIMM_NO_CHAIN_SHORTCUT", "0") != "1"):
                         shortcut = None
                         ds_spec = (x, p + "/downsample/0/kernel", p + "/downsample/1", emit_shortcut)
-                    elif (c.block == "bottleneck" and c.down_kernel_size == 1 and not gn
-                          and b.can_fold_shortcut(x, stride, out_ch)):
-                        # any other 1x1 shortcut convolution of a bottleneck (the strided first blocks of stages 2 - 4): its input
-                        # channels become further k-tiles of conv3 (tfimm_gemm_desc::a2) -- no shortcut tensor, no launch
+                    elif (c.down_kernel_size == 1 and not gn and b.can_fold_shortcut(x, stride, out_ch)):
+                        # any other 1x1 shortcut convolution (the strided first blocks of stages 2 - 4): its input channels become
+                        # further k-tiles of the block's last convolution -- conv3 of a bottleneck, the 3x3 conv2 of a basic block
+                        # (tfimm_gemm_desc::a2) -- no shortcut tensor, no launch
                         shortcut = None
                         fold_spec = (x, p + "/downsample/0/kernel", p + "/downsample/1", stride, emit_shortcut)
                     else:
@@ -309,7 +309,14 @@ class ResNet(Model):
                               cite="resnet.py:168-172")
                 if use_aa:
                     y = b.blur_pool(y, stride, cite="resnet.py:173-174")
-                y = conv_norm(y, p + "/conv2/kernel", p + "/bn2", padding=1, cite="resnet.py:176-186", **last)
+                if fold_spec is not None and not b.can_fold_shortcut(fold_spec[0], fold_spec[3], out_ch, y.C):
+                    shortcut, fold_spec = fold_spec[4](), None
+                    last = dict(residual=shortcut, act=act, act_after=True)
+                if fold_spec is not None:
+                    y = conv_norm(y, p + "/conv2/kernel", p + "/bn2", padding=1, act=act, fold_shortcut=fold_spec[:4],
+                                  cite="resnet.py:176-186 + 315-330")
+                else:
+                    y = conv_norm(y, p + "/conv2/kernel", p + "/bn2", padding=1, cite="resnet.py:176-186", **last)
             else:
                 y = conv_norm(x, p + "/conv1/kernel", p + "/bn1", act=act, cite="resnet.py:269-271")
                 k2 = p + "/conv2/kernel"

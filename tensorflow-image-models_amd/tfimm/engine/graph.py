@@ -392,6 +392,18 @@ class Builder:
             wt, bvec, kk, mode = pack.pack_conv(k, scale, shift, x.C, fp32=self.fp32)
             attrs.update(mode=mode, K=kk, H=x.H, W=x.W, Cin=x.C, KH=kh, KW=kw, stride=stride,
                          pad_t=pt, pad_l=pl, OH=OH, OW=OW)
+            if fold_shortcut is not None:          # the 3x3 conv2 of a basic block + its block's 1x1 shortcut convolution
+                x2, kernel2, bn2, stride2 = fold_shortcut
+                assert mode == 1 and self.can_fold_shortcut(x2, stride2, cout, x.C) and residual is None and remap is None
+                k2 = self.wget(kernel2)
+                assert k2.shape[:2] == (1, 1) and k2.shape[2] == x2.C and k2.shape[3] == cout
+                assert ((x2.H - 1) // stride2 + 1, (x2.W - 1) // stride2 + 1) == (OH, OW)
+                scale2, shift2 = self.bn(bn2, bn_eps)
+                wt2, _ = pack.pack_dense(k2.reshape(x2.C, cout) * scale2.reshape(1, cout), None)
+                wt = np.concatenate([wt, wt2], axis=1)
+                bvec = shift2 if bvec is None else bvec + shift2
+                attrs["dual"] = dict(K2=x2.C, lda2=x2.C, stride=stride2, H=x2.H, W=x2.W, OH=OH, OW=OW)
+                attrs["K_true"] = kh * kw * cin + x2.C
         consts["wt"] = p.new_const(wt, kernel)
         attrs["ldw"] = wt.shape[1]
         if bvec is not None:
@@ -414,7 +426,7 @@ class Builder:
         if attrs.get("dual"):
             ins.append(fold_shortcut[0])
         else:
-            assert fold_shortcut is None, "fold_shortcut needs a 1x1 / stride-1 convolution (see can_fold_shortcut)"
+            assert fold_shortcut is None, "fold_shortcut: a 1x1 convolution or a Cin % 8 == 0 gather (see can_fold_shortcut)"
         p.add("gemm", ins, out, consts, cite=cite, **attrs)
         if then_maxpool is not None:
             return self.maxpool(out, *then_maxpool, cite=cite)

@@ -200,6 +200,41 @@ def _dual_case(B, OH, OW, K1, K2, N, stride, seed, tile=0, act="relu"):
     return _err(_cpu(got), ref), TOL_BF16
 
 
+def _dual_conv_case(B, OH, OW, C1, C2, N, stride, seed, tile=0):
+    """... with a 3x3 / stride 1 / pad 1 GATHER as the first operand: conv2 of a BASIC block (resnet.py:176-186) + the block's
+    1x1 / stride-s shortcut convolution of the block input."""
+    import hip_ops as H
+    r = _rng(seed)
+    H2, W2 = OH * stride, OW * stride
+    M = B * OH * OW
+    h = _bf(r.standard_normal((B, OH, OW, C1)))
+    x = _bf(r.standard_normal((B, H2, W2, C2)))
+    kern = _bf(r.standard_normal((3, 3, C1, N)) / math.sqrt(9 * C1))
+    wd = _bf(r.standard_normal((C2, N)) / math.sqrt(C2))
+    bvec = r.standard_normal(N).astype(np.float32)
+    y = O.conv2d(O.zero_pad2d(torch.from_numpy(h), 1), torch.from_numpy(kern), None, stride=1).numpy().reshape(M, N)
+    xs = x[:, ::stride, ::stride, :].reshape(M, C2)
+    ref = np.maximum(y.astype(np.float64) + xs.astype(np.float64) @ wd.astype(np.float64) + bvec, 0.0)
+    wt1, _, K, mode = pack.pack_conv(kern, None, None, C1)
+    k2p = -(-C2 // 64) * 64
+    wt2 = np.zeros((N, k2p), np.uint16)
+    wt2[:, :C2] = pack.to_bf16_bits(wd.T)
+    wt = np.concatenate([wt1, wt2], axis=1)
+    conv = dict(mode=mode, B=B, H=OH, W=OW, Cin=C1, KH=3, KW=3, stride=1, pad_t=1, pad_l=1, OH=OH, OW=OW)
+    got = H.gemm(H.dev_bf16(h.reshape(-1, C1)), H.dev_bits(wt), N, K, conv=conv, bias=H.dev_f32(bvec), act="relu", tile_hint=tile,
+                 a2=H.dev_bf16(x.reshape(-1, C2)), a2_geom=None if stride == 1 else (stride, H2, W2, OH, OW))
+    H.sync()
+    return _err(_cpu(got), ref), TOL_BF16
+
+
+# ResNet-18's strided first blocks (3x3 conv2 gather + the 1x1 / stride-2 shortcut of the block input)
+CASES["gemm_dual_conv3x3_resnet18_stage2"] = lambda: _dual_conv_case(3, 28, 28, 128, 64, 128, 2, 160)
+CASES["gemm_dual_conv3x3_resnet18_stage4"] = lambda: _dual_conv_case(5, 7, 7, 512, 256, 512, 2, 161)
+CASES["gemm_dual_conv3x3_cin72_stride1"] = lambda: _dual_conv_case(2, 9, 11, 72, 40, 96, 1, 162)            # Cin % 64 != 0: per-piece tap division
+for _t in (21, 23, 25, 27):
+    CASES[f"gemm_dual_conv3x3_tile{_t}"] = lambda t=_t: _dual_conv_case(4, 14, 14, 64, 136, 264, 2, 170 + t, tile=t)
+
+
 # ResNet-50's three strided first blocks at small batch (stage 2: 128 + 256 -> 512 at 28 x 28; stage 3: 256 + 512 -> 1024; stage 4)
 CASES["gemm_dual_resnet_stage2_s2"] = lambda: _dual_case(3, 28, 28, 128, 256, 512, 2, 140)
 CASES["gemm_dual_resnet_stage3_s2"] = lambda: _dual_case(5, 14, 14, 256, 512, 1024, 2, 141)

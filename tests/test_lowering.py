@@ -362,7 +362,8 @@ def test_strided_shortcut_convolutions_become_a_second_operand_of_conv3(monkeypa
 @pytest.mark.parametrize("name,n", [("resnext50_32x4d", 3), ("wide_resnet50_2", 3), ("resnet101", 3),
                                     ("seresnet50", 0),      # the SE gate sits between conv3 and the add
                                     ("resnet50d", 0),       # average-pool shortcut: a 2 x 2 gather, not a 1 x 1 convolution
-                                    ("resnet18", 0),        # basic blocks: the last convolution is a 3 x 3 gather
+                                    ("resnet18", 3),        # basic blocks: the 3 x 3 conv2 gather takes the shortcut as its second operand
+                                    ("resnet34", 3),
                                     ("resnet50_gn", 0)])    # GroupNorm does not fold into the weights
 def test_which_configurations_fold_their_shortcut(name, n):
     _, prog = _kinds(name)
