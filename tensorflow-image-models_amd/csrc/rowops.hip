@@ -1067,7 +1067,10 @@ static int launch_dwconv_strip(const bf16_t* x, const float* w, const float* bia
 // images into a workgroup to reuse the weights measured 1.5x SLOWER).  w1 rows are read by whole waves and w2
 // ([rd][C]: the Keras layout of the expand conv) by consecutive threads -- all loads coalesced.  (256 threads and a
 // [C][rd] w2 walked row-per-thread took 67 us for C = 1632.)
-constexpr int SE_IMG = 1;
+#ifndef TFIMM_SE_IMG
+#define TFIMM_SE_IMG 1
+#endif
+constexpr int SE_IMG = TFIMM_SE_IMG;      // images per block (1: measured best -- see profiles/NOTES_r06.md 10)
 __global__ void __launch_bounds__(1024) se_gate_kernel(const void* __restrict__ sums_v, int sums_fixed, float inv_count,
                                                       const float* __restrict__ w1, const float* __restrict__ b1,
                                                       const float* __restrict__ w2, const float* __restrict__ b2,
