@@ -141,6 +141,11 @@ typedef struct tfimm_gemm_desc {
   const void* a2;         /* bf16 [B * a2_H * a2_W][lda2] */
   int32_t K2, lda2;       /* channels of the second operand (multiple of 8) and its pixel pitch in elements */
   int32_t a2_stride, a2_H, a2_W, a2_OH, a2_OW;
+  int32_t a2_window;      /* 0 / 1: the 1x1 view above.  w > 1: a w x w window of taps -- output row (b, oy, ox) reads the pixels
+                             (b, oy * a2_stride + dy, ox * a2_stride + dx), dy, dx < w, as w * w further operands of K2 channels each
+                             (taps in (dy, dx) order, each padded to whole 64-wide k-tiles in wt): the average-pool shortcut of
+                             ResNet-D, AveragePooling2D(2, 2) + 1x1 convolution (resnet.py:295-312) = a 2x2 / stride-2 convolution whose
+                             taps are the 1x1 kernel / 4.  The window must lie inside the image for every output pixel. */
 } tfimm_gemm_desc;
 
 TFIMM_API int tfimm_hip_gemm(const tfimm_gemm_desc* d, void* stream);

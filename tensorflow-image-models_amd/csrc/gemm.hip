@@ -205,14 +205,16 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       TFIMM_FAIL(TFIMM_EINVAL, "gemm: a second A operand needs a bf16 layer (dense or TFIMM_A_CONV) without residual / gate / LayerNorm / row remap");
     if (d.K2 <= 0 || (d.K2 & 7) || d.lda2 < d.K2 || (d.lda2 & 7) || ((uintptr_t)d.a2 & 15))
       TFIMM_FAIL(TFIMM_EINVAL, "gemm: a2 needs K2=%d %% 8 == 0, lda2=%d >= K2 and %% 8 == 0, a 16-byte aligned pointer", d.K2, d.lda2);
-    if (d.a2_stride < 1) TFIMM_FAIL(TFIMM_EINVAL, "gemm: a2_stride=%d", d.a2_stride);
-    if (d.a2_stride > 1) {
+    if (d.a2_stride < 1 || d.a2_window < 0 || d.a2_window > 4) TFIMM_FAIL(TFIMM_EINVAL, "gemm: a2_stride=%d a2_window=%d", d.a2_stride, d.a2_window);
+    const int a2w = d.a2_window > 1 ? d.a2_window : 1;
+    if (d.a2_stride > 1 || a2w > 1) {
       if (d.a2_H <= 0 || d.a2_W <= 0 || d.a2_OH <= 0 || d.a2_OW <= 0 || d.M % ((int64_t)d.a2_OH * d.a2_OW) ||
-          (d.a2_OH - 1) * d.a2_stride >= d.a2_H || (d.a2_OW - 1) * d.a2_stride >= d.a2_W)
-        TFIMM_FAIL(TFIMM_EINVAL, "gemm: a2 geometry %dx%d -> %dx%d at stride %d (M=%d)", d.a2_H, d.a2_W, d.a2_OH, d.a2_OW, d.a2_stride, d.M);
+          (d.a2_OH - 1) * d.a2_stride + a2w > d.a2_H || (d.a2_OW - 1) * d.a2_stride + a2w > d.a2_W)
+        TFIMM_FAIL(TFIMM_EINVAL, "gemm: a2 geometry %dx%d -> %dx%d at stride %d, window %d (M=%d)", d.a2_H, d.a2_W, d.a2_OH, d.a2_OW, d.a2_stride, a2w, d.M);
     }
     const int64_t kp = cdiv64(d.K, 64) * 64;
-    if (d.ldw < kp + d.K2) TFIMM_FAIL(TFIMM_EINVAL, "gemm: ldw=%d < %lld + K2=%d (the second operand's weights start at column ceil64(K))", d.ldw, (long long)kp, d.K2);
+    if (d.ldw < kp + (int64_t)(a2w * a2w - 1) * cdiv64(d.K2, 64) * 64 + d.K2)
+      TFIMM_FAIL(TFIMM_EINVAL, "gemm: ldw=%d too small for K=%d + %d taps of K2=%d (each part padded to 64)", d.ldw, d.K, a2w * a2w, d.K2);
   }
 
   // The LDS-DMA kernels address every tensor through a buffer descriptor with a 32-bit byte offset.  A plain
@@ -315,12 +317,14 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
     const int64_t res_bytes = d.residual ? ((res_rows - 1) * d.ldr + d.N) * 2 : 0;
     const bool scale = kmode == K_DENSE_SCALE;
     const bool dual = d.a2 != nullptr;
-    const int64_t a2_rows = !dual ? 0 : d.a2_stride > 1 ? (int64_t)(d.M / ((int64_t)d.a2_OH * d.a2_OW)) * d.a2_H * d.a2_W : d.M;
+    const int a2win = d.a2_window > 1 ? d.a2_window : 1;
+    const int64_t a2_rows = !dual ? 0 : (d.a2_stride > 1 || a2win > 1) ? (int64_t)(d.M / ((int64_t)d.a2_OH * d.a2_OW)) * d.a2_H * d.a2_W : d.M;
     const int64_t a2_bytes = dual ? ((a2_rows - 1) * d.lda2 + d.K2) * 2 : 0;
     const bool ok = (kmode == K_DENSE || kmode == K_CONV || scale) && (!hinted_other || dual) && !stream_disabled() && !dma_disabled() &&
                     d.ldw >= (int)(cdiv64(d.K, 64) * 64) && a_bytes <= 0x7fffff00LL && w_bytes <= 0x7fffff00LL &&
                     out_bytes <= 0x7fffff00LL && res_bytes <= 0x7fffff00LL && a2_bytes <= 0x7fffff00LL &&
-                    (!dual || ((kmode == K_DENSE || kmode == K_CONV) && d.ldw >= (int)(cdiv64(d.K, 64) * 64 + cdiv64(d.K2, 64) * 64)));
+                    (!dual || ((kmode == K_DENSE || kmode == K_CONV) &&
+                               d.ldw >= (int)(cdiv64(d.K, 64) * 64 + (int64_t)a2win * a2win * cdiv64(d.K2, 64) * 64)));
     if (ok) {
       const int fi = kmode == K_CONV ? 1 : 0;
       // vector epilogue: whole 16-byte groups per lane on aligned rows
@@ -435,6 +439,7 @@ extern "C" int tfimm_hip_gemm(const tfimm_gemm_desc* dp, void* stream) {
       if (grid > need) grid = need;
       ga.s_bytes = 0; ga.s_slots = ga.s_gp = 0;
       ga.a2 = (const bf16_t*)d.a2; ga.a2_bytes = (unsigned)a2_bytes;
+      ga.a2_window = a2win;
       ga.K2 = d.K2; ga.lda2 = d.lda2; ga.a2_stride = d.a2_stride; ga.a2_H = d.a2_H; ga.a2_W = d.a2_W; ga.a2_OH = d.a2_OH; ga.a2_OW = d.a2_OW;
       ga.ln_stats = d.ln_stats; ga.ln_c1 = d.ln_c1;
       ga.ln_stats_bytes = ln_in ? (unsigned)((int64_t)d.M * 8) : 0u;

@@ -53,6 +53,7 @@ struct GemmStreamArgs {
   const bf16_t* a2;
   unsigned a2_bytes;
   int K2, lda2, a2_stride, a2_H, a2_W, a2_OH, a2_OW;
+  int a2_window;     // taps per side of the second operand's window (1: a 1x1 view)
   // LNIN flavour (LayerNorm folded into this GEMM): per-row (mean, rstd) and the split column sums of the gamma-scaled weights
   const float* ln_stats;      // fp32 [M][2]
   const void* ln_c1;          // bf16 [N][2][8] correction fragments (pack.pack_ln_c1)
@@ -155,7 +156,8 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   const int s_gbytes = SCALE ? pa.s_gp * 1024 : 0;
 
   const int nk1 = (p.K + BK - 1) / BK;                          // k-tiles of the (first) A operand
-  const int nk = nk1 + (DUAL ? (pa.K2 + BK - 1) / BK : 0);      // DUAL: the second operand's follow (weights: column nk1 * 64 on)
+  const int nk2c = DUAL ? (pa.K2 + BK - 1) / BK : 0;            // DUAL: k-tiles of one tap of the second operand
+  const int nk = nk1 + nk2c * (DUAL ? pa.a2_window * pa.a2_window : 0);      // ... they follow the first operand's (weights: column nk1 * 64 on)
   const int lrow = lane >> 3;   // row within an 8-row DMA piece
   const int lpc = lane & 7;     // physical 16-byte chunk this lane fills
 
@@ -166,6 +168,8 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
   unsigned b_off[B_INSTR];
   int s_ky = 0, s_kx = 0, s_ci0 = 0;   // K_CONV + cin64: wave-uniform tap state of the next k-tile
   int s_b0 = 0;                        // SCALE: first image of the tile being issued (-1: no tile)
+  int s_k2 = 0, s_dx = 0;              // DUAL: k-tile inside the current tap of the second operand, the tap's column
+  unsigned s_tapoff = 0;               // ... and its byte offset (dy * a2_W + dx) * lda2 * 2
 
   auto a_chunk = [&](int j) -> int {    // logical 16-byte k-chunk this lane fetches for DMA piece j
     const int r = (wave * A_INSTR + j) * 8 + lrow;
@@ -206,7 +210,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
       }
       if (DUAL) {        // the second operand is dense rows whatever the first one is (a gather for the 3 x 3 conv2 of a basic block)
         int r2 = m;
-        if (pa.a2_stride > 1) {                      // (b, oy, ox) of the output row -> pixel (b, oy s, ox s) of the input image
+        if (pa.a2_stride > 1 || pa.a2_window > 1) {  // (b, oy, ox) of the output row -> pixel (b, oy s, ox s) of the input image
           const int mm = ok ? m : 0;
           const int ohw = pa.a2_OH * pa.a2_OW;
           const int b = mm / ohw, rem = mm - b * ohw;
@@ -229,6 +233,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
       b_off[j] = (valid && n < p.N) ? (unsigned)(((size_t)nsrc * p.ldw + chunk * 8) * 2) : kOobOffset;
     }
     s_ky = s_kx = s_ci0 = 0;
+    if (DUAL) { s_k2 = 0; s_dx = 0; s_tapoff = 0u; }
     if (SCALE) s_b0 = valid ? m0 / p.rows_per_image : -1;
   };
 
@@ -249,13 +254,12 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
       const int j = piece;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(sb + (wave * B_INSTR + j) * 1024), 16,
                                                (int)b_off[j], kbytes, 0, 0);
-    } else if (DUAL && kt >= nk1) {      // (wave-uniform) a k-tile of the second operand: dense rows
+    } else if (DUAL && kt >= nk1) {      // (wave-uniform) a k-tile of the second operand: dense rows of tap (s_tapoff), k-tile s_k2
       const int j = piece - B_INSTR;
-      const int kt2 = kt - nk1;
-      const bool kok = (kt2 * BK + a_chunk(j) * 8) < pa.K2;
-      const unsigned off = kok ? a_off2[j] : kOobOffset;
+      const bool kok = (s_k2 * BK + a_chunk(j) * 8) < pa.K2;
+      const unsigned off = (kok && a_off2[j] != kOobOffset) ? a_off2[j] + s_tapoff : kOobOffset;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a2, (lds_ptr_t)(sa + (wave * A_INSTR + j) * 1024), 16,
-                                               (int)off, kt2 * 128, 0, 0);
+                                               (int)off, s_k2 * 128, 0, 0);
     } else if (KMODE == K_DENSE) {
       const int j = piece - B_INSTR;
       const bool kok = (kt * BK + a_chunk(j) * 8) < p.K;
@@ -285,7 +289,14 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
     }
   };
   // after the last piece of a step: advance the scalar tap state of the NHWC gather
-  auto issue_done = [&]() __attribute__((always_inline)) {
+  auto issue_done = [&](int kt) __attribute__((always_inline)) {
+    if (DUAL && kt >= nk1) {                  // next k-tile of the second operand: same tap, or the next tap of its window
+      if (++s_k2 == nk2c) {
+        s_k2 = 0;
+        if (++s_dx == pa.a2_window) { s_dx = 0; s_tapoff += (unsigned)((pa.a2_W - pa.a2_window + 1) * pa.lda2 * 2); }
+        else s_tapoff += (unsigned)(pa.lda2 * 2);
+      }
+    }
     if (KMODE == K_CONV && pa.cin64) {        // (DUAL: the steps behind the last filter tap run past it harmlessly -- setup_issue resets the state per tile)
       s_ci0 += BK;
       if (s_ci0 >= p.Cin) {
@@ -311,7 +322,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) gemm_stream_kernel(cons
 #pragma unroll
     for (int q = 0; q < N_PIECES; ++q) issue_piece(q, kt, stage);
     if (SCALE) issue_gate(kt, stage);
-    issue_done();
+    issue_done(kt);
   };
 
   const int frow = lane & 31;

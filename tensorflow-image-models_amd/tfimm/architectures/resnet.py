@@ -269,9 +269,16 @@ class ResNet(Model):
                     if stride == 1:
                         shortcut = conv_norm(x, kname, p + "/downsample/2", cite="resnet.py:295-312")
                     elif stride == 2 and x.H % 2 == 0 and x.W % 2 == 0:
-                        folded = b.define(kname + ":avgpool2x2", np.tile(b.wget(kname) * 0.25, (2, 2, 1, 1)))
-                        shortcut = conv_norm(x, folded, p + "/downsample/2", stride=2, padding="valid", flops_k=x.C,
+                        def emit_shortcut(x=x, p=p, kname=kname):
+                            folded = b.define(kname + ":avgpool2x2", np.tile(b.wget(kname) * 0.25, (2, 2, 1, 1)))
+                            return conv_norm(x, folded, p + "/downsample/2", stride=2, padding="valid", flops_k=x.C,
                                              cite="resnet.py:295-312")
+                        if not gn and b.can_fold_shortcut(x, 2, out_ch):
+                            # ... or not even that: the four taps as a 2 x 2 window of the block's last convolution's second operand
+                            shortcut = None
+                            fold_spec = (x, kname, p + "/downsample/2", 2, emit_shortcut, 2)
+                        else:
+                            shortcut = emit_shortcut()
                     else:
                         pooled = b.avg_pool(x, 2, stride, cite="resnet.py:299-301")
                         shortcut = conv_norm(pooled, kname, p + "/downsample/2", cite="resnet.py:304-312")
@@ -313,7 +320,7 @@ class ResNet(Model):
                     shortcut, fold_spec = fold_spec[4](), None
                     last = dict(residual=shortcut, act=act, act_after=True)
                 if fold_spec is not None:
-                    y = conv_norm(y, p + "/conv2/kernel", p + "/bn2", padding=1, act=act, fold_shortcut=fold_spec[:4],
+                    y = conv_norm(y, p + "/conv2/kernel", p + "/bn2", padding=1, act=act, fold_shortcut=fold_spec[:4] + fold_spec[5:],
                                   cite="resnet.py:176-186 + 315-330")
                 else:
                     y = conv_norm(y, p + "/conv2/kernel", p + "/bn2", padding=1, cite="resnet.py:176-186", **last)
@@ -365,7 +372,7 @@ class ResNet(Model):
                         shortcut, fold_spec = fold_spec[4](), None          # conv3's own input is not 16-byte aligned: the plain form
                         last = dict(residual=shortcut, act=act, act_after=True)
                     if fold_spec is not None:
-                        y = conv_norm(y, p + "/conv3/kernel", p + "/bn3", act=act, fold_shortcut=fold_spec[:4],
+                        y = conv_norm(y, p + "/conv3/kernel", p + "/bn3", act=act, fold_shortcut=fold_spec[:4] + fold_spec[5:],
                                       cite="resnet.py:280-290 + 315-330")
                     else:
                         y = conv_norm(y, p + "/conv3/kernel", p + "/bn3", cite="resnet.py:280-290", **last)

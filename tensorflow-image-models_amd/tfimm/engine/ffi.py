@@ -41,6 +41,7 @@ class GemmDesc(C.Structure):
         # ABI v4: a second A operand (the shortcut convolution of a residual block folded into its last 1x1 convolution)
         ("a2", C.c_void_p), ("K2", C.c_int32), ("lda2", C.c_int32),
         ("a2_stride", C.c_int32), ("a2_H", C.c_int32), ("a2_W", C.c_int32), ("a2_OH", C.c_int32), ("a2_OW", C.c_int32),
+        ("a2_window", C.c_int32),
     ]
 
 

@@ -375,35 +375,24 @@ class Builder:
                                        fp32=self.fp32)
             attrs.update(mode=0, K=cin, lda=x.C, a_rows_per_image=x.rows)
             if fold_shortcut is not None:
-                x2, kernel2, bn2, stride2 = fold_shortcut
-                assert self.can_fold_shortcut(x2, stride2, cout, cin) and residual is None and a_scale is None and remap is None
-                k2 = self.wget(kernel2)
-                assert k2.shape[:2] == (1, 1) and k2.shape[2] == x2.C and k2.shape[3] == cout
-                oh2, ow2 = (x2.H - 1) // stride2 + 1, (x2.W - 1) // stride2 + 1        # 1x1 / stride s, no padding
-                assert (oh2, ow2) == (OH, OW), (oh2, ow2, OH, OW)
-                scale2, shift2 = self.bn(bn2, bn_eps)
-                wt2, _ = pack.pack_dense(k2.reshape(x2.C, cout) * scale2.reshape(1, cout), None)
-                wt = np.concatenate([wt, wt2], axis=1)          # [N][ceil64(K) + ceil64(K2)]: the second operand's k-tiles follow
+                assert residual is None and a_scale is None and remap is None
+                wt2, shift2, du = self._shortcut_operand(fold_shortcut, cout, cin, OH, OW, bn_eps)
+                wt = np.concatenate([wt, wt2], axis=1)          # [N][ceil64(K) + taps * ceil64(K2)]: the second operand's k-tiles follow
                 bvec = shift2 if bvec is None else bvec + shift2
-                attrs["dual"] = dict(K2=x2.C, lda2=x2.C, stride=stride2, H=x2.H, W=x2.W, OH=OH, OW=OW)
-                attrs["K_true"] = cin + x2.C
+                attrs["dual"] = du
+                attrs["K_true"] = cin + du["K2"]
         else:
             assert a_scale is None
             wt, bvec, kk, mode = pack.pack_conv(k, scale, shift, x.C, fp32=self.fp32)
             attrs.update(mode=mode, K=kk, H=x.H, W=x.W, Cin=x.C, KH=kh, KW=kw, stride=stride,
                          pad_t=pt, pad_l=pl, OH=OH, OW=OW)
             if fold_shortcut is not None:          # the 3x3 conv2 of a basic block + its block's 1x1 shortcut convolution
-                x2, kernel2, bn2, stride2 = fold_shortcut
-                assert mode == 1 and self.can_fold_shortcut(x2, stride2, cout, x.C) and residual is None and remap is None
-                k2 = self.wget(kernel2)
-                assert k2.shape[:2] == (1, 1) and k2.shape[2] == x2.C and k2.shape[3] == cout
-                assert ((x2.H - 1) // stride2 + 1, (x2.W - 1) // stride2 + 1) == (OH, OW)
-                scale2, shift2 = self.bn(bn2, bn_eps)
-                wt2, _ = pack.pack_dense(k2.reshape(x2.C, cout) * scale2.reshape(1, cout), None)
+                assert mode == 1 and residual is None and remap is None
+                wt2, shift2, du = self._shortcut_operand(fold_shortcut, cout, x.C, OH, OW, bn_eps)
                 wt = np.concatenate([wt, wt2], axis=1)
                 bvec = shift2 if bvec is None else bvec + shift2
-                attrs["dual"] = dict(K2=x2.C, lda2=x2.C, stride=stride2, H=x2.H, W=x2.W, OH=OH, OW=OW)
-                attrs["K_true"] = kh * kw * cin + x2.C
+                attrs["dual"] = du
+                attrs["K_true"] = kh * kw * cin + du["K2"]
         consts["wt"] = p.new_const(wt, kernel)
         attrs["ldw"] = wt.shape[1]
         if bvec is not None:
@@ -431,6 +420,23 @@ class Builder:
         if then_maxpool is not None:
             return self.maxpool(out, *then_maxpool, cite=cite)
         return out
+
+    def _shortcut_operand(self, spec, cout: int, cin: int, OH: int, OW: int, bn_eps: float):
+        """Weights [N][taps * ceil64(K2)], folded-BN shift and descriptor fields of a shortcut convolution taken as the second A
+        operand: ``spec = (x2, kernel2, bn2, stride2[, window])`` -- a 1x1 / stride-s convolution + BatchNorm (resnet.py:315-330), or,
+        ``window`` = 2, ResNet-D's AveragePooling2D(2, 2) + 1x1 convolution + BatchNorm (resnet.py:295-312) as the 2x2 / stride-2
+        convolution whose four taps are the 1x1 kernel / 4 (exact in bf16: a power of two)."""
+        x2, kernel2, bn2, stride2 = spec[:4]
+        window = spec[4] if len(spec) > 4 else 1
+        assert self.can_fold_shortcut(x2, stride2, cout, cin)
+        k2 = self.wget(kernel2)
+        assert k2.shape[:2] == (1, 1) and k2.shape[2] == x2.C and k2.shape[3] == cout
+        assert ((x2.H - window) // stride2 + 1, (x2.W - window) // stride2 + 1) == (OH, OW), (x2.H, x2.W, window, stride2, OH, OW)
+        scale2, shift2 = self.bn(bn2, bn_eps)
+        tap = k2.reshape(x2.C, cout) * scale2.reshape(1, cout) / float(window * window)
+        wt2 = np.concatenate([pack.pack_dense(tap, None)[0]] * (window * window), axis=1)
+        du = dict(K2=x2.C, lda2=x2.C, stride=stride2, H=x2.H, W=x2.W, OH=OH, OW=OW, window=window if window > 1 else 0)
+        return wt2, shift2, du
 
     def can_fold_shortcut(self, x2: TRef, stride2: int, cout: int, cin: int = 8) -> bool:
         """Whether ``conv(..., fold_shortcut=(x2, ...))`` can take a 1x1 / stride-``stride2`` shortcut convolution of ``x2`` as a
@@ -1150,6 +1156,7 @@ class Plan:
                     idx += 1
                     d.K2, d.lda2, d.a2_stride = du["K2"], du["lda2"], du["stride"]
                     d.a2_H, d.a2_W, d.a2_OH, d.a2_OW = du["H"], du["W"], du["OH"], du["OW"]
+                    d.a2_window = du.get("window", 0)
                 d.tile_hint = tune.lookup(d)
                 self._keepalive.append(d)
                 self._gemm_descs.append(d)

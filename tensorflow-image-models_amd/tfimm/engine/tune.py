@@ -43,7 +43,7 @@ def key_of(d) -> str:
         d.mode, d.M, d.N, d.K, d.lda, d.ldc, d.H, d.W, d.Cin, d.KH, d.KW, d.stride,
         1 if d.residual else 0, d.out_f32, d.act, 1 if d.a_scale else 0))
     if getattr(d, "a2", None):          # a second A operand (ABI v4): K2 more channels, read at a2_stride
-        key += f":d{int(d.K2)}s{int(d.a2_stride)}"
+        key += f":d{int(d.K2)}s{int(d.a2_stride)}" + (f"w{int(d.a2_window)}" if getattr(d, "a2_window", 0) > 1 else "")
     return key + ":ln" if getattr(d, "ln_stats", None) else key
 
 

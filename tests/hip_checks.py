@@ -235,6 +235,39 @@ for _t in (21, 23, 25, 27):
     CASES[f"gemm_dual_conv3x3_tile{_t}"] = lambda t=_t: _dual_conv_case(4, 14, 14, 64, 136, 264, 2, 170 + t, tile=t)
 
 
+def _dual_window_case(B, OH, OW, K1, K2, N, seed, tile=0):
+    """... with a 2 x 2 / stride-2 WINDOW as the second operand (a2_window = 2): ResNet-D's AveragePooling2D(2, 2) + 1x1 convolution
+    shortcut (resnet.py:295-312) folded into conv3 -- four taps of the 1x1 kernel / 4."""
+    import hip_ops as H
+    r = _rng(seed)
+    H2, W2 = 2 * OH, 2 * OW
+    M = B * OH * OW
+    h = _bf(r.standard_normal((M, K1)))
+    x = _bf(r.standard_normal((B, H2, W2, K2)))
+    w3 = _bf(r.standard_normal((K1, N)) / math.sqrt(K1))
+    wd = _bf(r.standard_normal((K2, N)) / math.sqrt(K2))
+    bvec = r.standard_normal(N).astype(np.float32)
+    pooled = x.reshape(B, OH, 2, OW, 2, K2).astype(np.float64).mean(axis=(2, 4)).reshape(M, K2)
+    ref = np.maximum(h.astype(np.float64) @ w3.astype(np.float64) + pooled @ wd.astype(np.float64) + bvec, 0.0)
+    k1p, k2p = -(-K1 // 64) * 64, -(-K2 // 64) * 64
+    wt = np.zeros((N, k1p + 4 * k2p), np.float32)
+    wt[:, :K1] = w3.T
+    for t in range(4):
+        wt[:, k1p + t * k2p:k1p + t * k2p + K2] = wd.T * 0.25
+    got = H.gemm(H.dev_bf16(h), H.dev_bits(pack.to_bf16_bits(wt)), N, K1, bias=H.dev_f32(bvec), act="relu", tile_hint=tile,
+                 a2=H.dev_bf16(x.reshape(-1, K2)), a2_geom=(2, H2, W2, OH, OW, 2))
+    H.sync()
+    return _err(_cpu(got), ref), TOL_BF16
+
+
+# resnet50d's strided first blocks (stage 2: conv3 128 -> 512 + avg-pooled 256 -> 512)
+CASES["gemm_dual_window2_resnet50d_stage2"] = lambda: _dual_window_case(3, 28, 28, 128, 256, 512, 180)
+CASES["gemm_dual_window2_resnet50d_stage4"] = lambda: _dual_window_case(6, 7, 7, 512, 1024, 2048, 181)
+CASES["gemm_dual_window2_ragged"] = lambda: _dual_window_case(2, 5, 9, 72, 40, 96, 182)             # K2 = 40: taps padded to 64 each
+for _t in (21, 23, 25, 27):
+    CASES[f"gemm_dual_window2_tile{_t}"] = lambda t=_t: _dual_window_case(4, 14, 14, 192, 136, 264, 183 + t, tile=t)
+
+
 # ResNet-50's three strided first blocks at small batch (stage 2: 128 + 256 -> 512 at 28 x 28; stage 3: 256 + 512 -> 1024; stage 4)
 CASES["gemm_dual_resnet_stage2_s2"] = lambda: _dual_case(3, 28, 28, 128, 256, 512, 2, 140)
 CASES["gemm_dual_resnet_stage3_s2"] = lambda: _dual_case(5, 14, 14, 256, 512, 1024, 2, 141)

@@ -49,7 +49,7 @@ def gemm(a, wt, N, K, *, M=None, bias=None, residual=None, out=None, act="", act
          rows_per_image=0, tile_hint=0, out_rows=None, a_byte_offset=0, out_byte_offset=0, ln_stats=None, ln_c1=None,
          a2=None, a2_geom=None):
     """conv: dict(mode, B, H, W, Cin, KH, KW, stride, pad_t, pad_l, OH, OW).
-    a2: second A operand [rows2][K2] (tfimm_gemm_desc::a2); a2_geom = (stride, H, W, OH, OW) for a strided row view."""
+    a2: second A operand [rows2][K2] (tfimm_gemm_desc::a2); a2_geom = (stride, H, W, OH, OW[, window]) for a strided row view (window > 1: w x w taps)."""
     d = ffi.GemmDesc()
     if conv is None:
         M = M if M is not None else a.shape[0]
@@ -92,7 +92,8 @@ def gemm(a, wt, N, K, *, M=None, bias=None, residual=None, out=None, act="", act
         d.a2, d.K2, d.lda2 = ptr(a2), a2.shape[-1], a2.shape[-1]
         d.a2_stride = 1
         if a2_geom is not None:
-            d.a2_stride, d.a2_H, d.a2_W, d.a2_OH, d.a2_OW = a2_geom
+            d.a2_stride, d.a2_H, d.a2_W, d.a2_OH, d.a2_OW = a2_geom[:5]
+            d.a2_window = a2_geom[5] if len(a2_geom) > 5 else 0
     if tile_hint == "table":        # what the engine would launch for this shape (tfimm/engine/gemm_tune.json)
         from tfimm.engine import tune
         tile_hint = tune.lookup(d)

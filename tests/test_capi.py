@@ -64,8 +64,8 @@ def test_gemm_desc_layout_matches_header():
         parts = decl.replace("*", " ").split(None, 1)[1] if not decl.startswith("const") else decl.replace("*", " ").split(None, 2)[2]
         names += [n.strip() for n in parts.split(",")]
     assert names == [f[0] for f in ffi.GemmDesc._fields_], names
-    # 6 pointers, 30 int32 (168 bytes: already a multiple of 8), 2 pointers; ABI v4: 1 pointer, 7 int32 (+ 4 bytes of tail padding)
-    assert ctypes.sizeof(ffi.GemmDesc) == 6 * 8 + 30 * 4 + 2 * 8 + 8 + 7 * 4 + 4
+    # 6 pointers, 30 int32 (168 bytes: already a multiple of 8), 2 pointers; ABI v4: 1 pointer, 8 int32
+    assert ctypes.sizeof(ffi.GemmDesc) == 6 * 8 + 30 * 4 + 2 * 8 + 8 + 8 * 4
     # 3 pointers, 4 int32, float, 4 int32 (= 60, padded to 64 for the pointer that follows), 1 pointer
     assert ctypes.sizeof(ffi.AttnDesc) == 64 + 8
 

@@ -38,8 +38,25 @@ def test_deep_stems_stay_unfused_and_avg_down_is_one_folded_conv(name):
     convolution whose taps are the 1x1 kernel / 4; deep stems never take the fused 7x7 stem kernel."""
     kinds, prog = _kinds(name)
     assert "stem_pool" not in kinds and kinds.count("maxpool") <= 1
+    # round 6: the four taps are a 2 x 2 window of the SECOND operand of the block's last convolution (tfimm_gemm_desc::a2_window)
+    # -- except behind an SE gate (resnetrs50), where the shortcut stays the folded 2 x 2 convolution of its own
+    own = [op for op in prog.ops if op.kind == "gemm" and op.attrs.get("KH") == 2 and op.attrs.get("stride") == 2]
+    duals = [op for op in prog.ops if op.kind == "gemm" and op.attrs.get("dual")]
+    assert (len(own), len(duals)) == ((3, 0) if name == "resnetrs50" else (0, 3))      # the three strided stage transitions
+    for op in own:
+        assert op.attrs["K"] == 4 * op.attrs["Cin"] and op.attrs["OH"] * 2 == op.attrs["H"]
+    for op in duals:
+        du = op.attrs["dual"]
+        assert du["window"] == 2 and du["stride"] == 2 and (du["H"], du["W"]) == (2 * du["OH"], 2 * du["OW"])
+        assert op.attrs["ldw"] == -(-op.attrs["K"] // 64) * 64 + 4 * (-(-du["K2"] // 64) * 64)
+
+
+@pytest.mark.parametrize("name", ["resnet26d"])
+def test_avg_down_as_its_own_folded_conv_when_the_fold_is_off(name, monkeypatch):
+    monkeypatch.setenv("TFIMM_NO_FOLD_SHORTCUT", "1")
+    kinds, prog = _kinds(name)
     folded = [op for op in prog.ops if op.kind == "gemm" and op.attrs.get("KH") == 2 and op.attrs.get("stride") == 2]
-    assert len(folded) == 3                                   # the three strided stage transitions
+    assert len(folded) == 3
     for op in folded:
         assert op.attrs["K"] == 4 * op.attrs["Cin"] and op.attrs["OH"] * 2 == op.attrs["H"]
 
@@ -52,8 +69,8 @@ def test_avg_down_at_odd_sizes_pools_explicitly():
     prog = m.program(200, 200)           # 200 -> stem 100 -> pool 50 -> 25 (odd) -> 13 (odd) -> 7
     pools = [op for op in prog.ops if op.kind == "avg_pool"]
     assert [(op.attrs["H"], prog.tensors[op.output].H) for op in pools] == [(25, 13), (13, 7)]
-    folded = [op for op in prog.ops if op.kind == "gemm" and op.attrs.get("KH") == 2 and op.attrs.get("stride") == 2]
-    assert len(folded) == 1 and folded[0].attrs["H"] == 50
+    folded = [op for op in prog.ops if op.kind == "gemm" and (op.attrs.get("dual") or {}).get("window") == 2]
+    assert len(folded) == 1 and folded[0].attrs["dual"]["H"] == 50
 
 
 def test_environment_switch_keeps_the_two_op_path(monkeypatch):
@@ -361,7 +378,8 @@ def test_strided_shortcut_convolutions_become_a_second_operand_of_conv3(monkeypa
 
 @pytest.mark.parametrize("name,n", [("resnext50_32x4d", 3), ("wide_resnet50_2", 3), ("resnet101", 3),
                                     ("seresnet50", 0),      # the SE gate sits between conv3 and the add
-                                    ("resnet50d", 0),       # average-pool shortcut: a 2 x 2 gather, not a 1 x 1 convolution
+                                    ("resnet50d", 3),       # average-pool shortcut: four taps of a 2 x 2 window as the second operand
+                                    ("seresnet152d", 0),    # ... but not behind an SE gate
                                     ("resnet18", 3),        # basic blocks: the 3 x 3 conv2 gather takes the shortcut as its second operand
                                     ("resnet34", 3),
                                     ("resnet50_gn", 0)])    # GroupNorm does not fold into the weights

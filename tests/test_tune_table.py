@@ -36,7 +36,7 @@ def test_committed_table_is_well_formed():
     valid = {0} | set(range(1, 7)) | set(range(11, 17)) | set(range(21, 32))
     for key, hint in table.items():
         fields = key[:-3].split(":") if key.endswith(":ln") else key.split(":")
-        dual = re.fullmatch(r"d(\d+)s(\d+)", fields[-1])      # a second A operand (ABI v4): ":d<K2>s<stride>"
+        dual = re.fullmatch(r"d(\d+)s(\d+)(?:w(\d+))?", fields[-1])      # a second A operand (ABI v4): ":d<K2>s<stride>"
         if dual:
             fields = fields[:-1]
             assert hint in tune.DUAL_CANDIDATES and fields[0] == "0" and int(dual.group(1)) % 8 == 0, (key, hint)
